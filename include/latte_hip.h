@@ -1,0 +1,145 @@
+/* liblatte_hip.so -- C-ABI of the MI355X (gfx950) sparse-voxel hot path of Latte.
+ *
+ * The reference (AronCao49/Latte) has no FFI layer: the boundary it consumes is the Python import
+ * surface of two third-party wheels (torchsparse v1.4.0, torch_scatter) plus its own
+ * latte/models/hr_module.py.  Every entry point below names the reference interface it replaces
+ * (file:line under /root/reference).  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *  - plain device pointers + element counts + hipStream_t; no torch types
+ *  - return 0 on success, <0 on error (LT_ERR_*); text via lt_last_error() (thread-local)
+ *  - the library never allocates outputs: the caller owns every buffer.  Data-dependent output sizes:
+ *    the caller passes buffers of the documented maximum capacity and the call returns the count
+ *    through a HOST pointer (those calls synchronise `stream`; they are marked [sync])
+ *  - workspaces are opaque byte buffers sized by the matching *_workspace_bytes() query
+ *  - feature matrices are row-major fp32 [rows, channels]; coordinates are int32 [rows,4] = (x,y,z,batch)
+ *  - one caller thread per device; calls on different devices/streams are independent
+ */
+#ifndef LATTE_HIP_H
+#define LATTE_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* lt_stream_t; /* == hipStream_t */
+
+const char* lt_last_error(void);
+int lt_version(void);
+
+/* ------------------------------------------------------------------ hashing / tables
+ * torchsparse.nn.functional.sphash(coords[, offsets])  (latte/models/torchsparse_utils.py:15,40,45,68,73)
+ * out[k*n+i] = fold60(FNV1a64(x+ox_k, y+oy_k, z+oz_k, b)); K==0 -> out[i] without offsets. */
+int lt_sphash(const int32_t* coords, int64_t n, const int32_t* offsets, int32_t K, int64_t* out, lt_stream_t stream);
+
+/* torchsparse.nn.functional.sphashquery(queries, references)  (torchsparse_utils.py:17,46,74)
+ * build: table over `keys` (value = row index; duplicate keys keep the smallest index)
+ * query: out[i] = index of queries[i] in keys, -1 on miss. `n_build` must be the n given to build. */
+int64_t lt_table_bytes(int64_t n);
+int lt_hash_build(const int64_t* keys, int64_t n, void* table, int64_t table_bytes, lt_stream_t stream);
+int lt_hash_query(const int64_t* queries, int64_t q, const void* table, int64_t n_build, int64_t* out,
+                  lt_stream_t stream);
+
+/* torchsparse.nn.functional.spcount(idx, num)  (torchsparse_utils.py:18,47): histogram ignoring idx<0 */
+int lt_spcount(const int32_t* idx, int64_t n, int32_t* out, int64_t num, lt_stream_t stream);
+
+/* np.unique(keys, return_index, return_inverse) / torch.unique(sorted) on non-negative int64 keys:
+ * (hr_module.py:87-89; torchsparse.utils.quantize.sparse_quantize at semantic_kitti_dataloader.py:562;
+ *  torch.unique(pc_hash) at torchsparse_utils.py:16).
+ * out_keys/out_first have capacity n, out_inverse n (any may be NULL). key_bits = number of significant
+ * low bits (<=63) -> fewer radix passes.  *count (HOST) receives V.  [sync] */
+int64_t lt_unique_workspace_bytes(int64_t n);
+int lt_unique_sorted(const int64_t* keys, int64_t n, int32_t key_bits, void* ws, int64_t ws_bytes, int64_t* out_keys,
+                     int64_t* out_first, int64_t* out_inverse, int64_t* count, lt_stream_t stream);
+
+/* ------------------------------------------------------------------ voxel keys
+ * ravel keys of the dataloader quantize contract a1: coords = round(p*scale) - min is done by the caller
+ * (torch), this packs non-negative int coords (<2^20 each) into a lexicographic (x,y,z) key.
+ * (torchsparse ravel_hash as copied in hr_module.py:58-71: ORDER is lexicographic in (x,y,z)). */
+int lt_pack_xyz_keys(const int32_t* coords3, int64_t n, int64_t* keys, lt_stream_t stream);
+
+/* ------------------------------------------------------------------ kernel maps (spnn.Conv3d internals)
+ * F.spdownsample(coords, stride=2, kernel=2, tensor_stride): coords//s*s, unique rows sorted by (b,x,y,z)
+ * (used by spnn.Conv3d(stride=2): latte/models/basic_blocks.py:17 via spvcnn.py:36,42,48,54).
+ * out_coords capacity = V rows. [sync] */
+int64_t lt_downsample_workspace_bytes(int64_t V);
+int lt_downsample_coords(const int32_t* coords, int64_t V, int32_t sample_stride, void* ws, int64_t ws_bytes,
+                         int32_t* out_coords, int64_t* count, lt_stream_t stream);
+
+/* Neighbour table of one conv: results[k*Vout+o] = row of the input voxel at coords_out[o]+offsets[k], or -1.
+ * (= torchsparse `results = sphashquery(sphash(coords_out, offsets), sphash(coords_in))` inside conv3d;
+ * reference call sites basic_blocks.py:17,34,51,58 and spvcnn.py:30,32). No sync. */
+int64_t lt_kmap_workspace_bytes(int64_t Vin);
+int lt_kmap_build(const int32_t* coords_in, int64_t Vin, const int32_t* coords_out, int64_t Vout,
+                  const int32_t* offsets, int32_t K, void* ws, int64_t ws_bytes, int32_t* results,
+                  lt_stream_t stream);
+/* torchsparse (nbmaps [M,2]=(in,out) k-major/out-ascending, nbsizes[K]) derived from `results`
+ * (nonzero(results != -1) order).  nbmaps capacity K*Vout rows.  [sync] */
+int64_t lt_kmap_pairs_workspace_bytes(int64_t K, int64_t Vout);
+int lt_kmap_pairs(const int32_t* results, int32_t K, int64_t Vout, void* ws, int64_t ws_bytes, int32_t* nbmaps,
+                  int32_t* nbsizes, int64_t* M, lt_stream_t stream);
+/* reverse table for transposed conv / backward: rev[k*Vin+i] = o where results[k*Vout+o] == i, else -1 */
+int lt_kmap_reverse(const int32_t* results, int32_t K, int64_t Vout, int64_t Vin, int32_t* rev, lt_stream_t stream);
+
+/* ------------------------------------------------------------------ sparse convolution
+ * spnn.Conv3d forward / backward-input (basic_blocks.py:17,34,51,58,68; spvcnn.py:30,32):
+ *   out[o,:] = sum_k in[nbr[k,o],:] @ Wk      (rows with nbr<0 contribute nothing)
+ * fp32 in / fp32 accumulate on v_mfma_f32_16x16x4_f32, output-stationary (no scatter, no atomics).
+ * Weights must first be packed into MFMA-fragment order:
+ *   mode 0: Wk            (forward, weight [K,Cin,Cout])
+ *   mode 1: Wk^T          (transposed conv fwd's backward / strided conv backward: use with lt_kmap_reverse)
+ *   mode 2: W(K-1-k)^T    (backward-input of a submanifold stride-1 conv on the SAME table)
+ * For modes 1,2 the packed matrix maps Cout -> Cin channels (swap Cin/Cout in lt_spconv_fwd).
+ * Cin % 4 == 0 and Cout % 16 == 0 required; `order` (optional, [Vout]) is a processing permutation of the
+ * output rows (locality / skip rate), results do not depend on it. */
+int64_t lt_spconv_packed_floats(int32_t K, int32_t Cin, int32_t Cout);
+int lt_spconv_pack_weights(const float* W, int32_t K, int32_t Cin, int32_t Cout, int32_t mode, float* packed,
+                           lt_stream_t stream);
+int lt_spconv_fwd(const float* in, const float* packed, const int32_t* nbr, const int32_t* order, float* out,
+                  int64_t Vin, int64_t Vout, int32_t Cin, int32_t Cout, int32_t K, lt_stream_t stream);
+/* dW[k] = sum over pairs in[nbr[k,o],:]^T (x) dout[o,:]   (only needed when TRAIN.UPDATE_PARAMS == "all") */
+int lt_spconv_bwd_weight(const float* in, const float* dout, const int32_t* nbr, float* dW, int64_t Vin,
+                         int64_t Vout, int32_t Cin, int32_t Cout, int32_t K, lt_stream_t stream);
+
+/* ------------------------------------------------------------------ BatchNorm(batch stats)+ReLU+residual
+ * spnn.BatchNorm + spnn.ReLU + skip add (basic_blocks.py:22-23,56-57,64,69,72,75); TTA forces batch
+ * statistics (latte/common/utils/ema_util.py:26-29).  var is the biased variance. */
+int64_t lt_bn_workspace_bytes(int64_t V, int32_t C);
+int lt_bn_stats(const float* x, int64_t V, int32_t C, void* ws, int64_t ws_bytes, float* mean, float* var,
+                lt_stream_t stream);
+int lt_bn_apply(const float* x, const float* mean, const float* var, const float* gamma, const float* beta,
+                float eps, const float* residual, int32_t relu, float* y, int64_t V, int32_t C,
+                lt_stream_t stream);
+/* g = dy * (y>0 if relu);  sum_g[c] = sum g;  sum_gx[c] = sum g*xhat */
+int lt_bn_bwd_reduce(const float* dy, const float* x, const float* y, const float* mean, const float* var,
+                     float eps, int32_t relu, int64_t V, int32_t C, void* ws, int64_t ws_bytes, float* sum_g,
+                     float* sum_gx, lt_stream_t stream);
+/* dx = gamma*rstd*(g - sum_g/V - xhat*sum_gx/V); dres = g (optional) */
+int lt_bn_bwd_apply(const float* dy, const float* x, const float* y, const float* mean, const float* var,
+                    const float* gamma, float eps, int32_t relu, const float* sum_g, const float* sum_gx,
+                    float* dx, float* dres, int64_t V, int32_t C, lt_stream_t stream);
+
+/* ------------------------------------------------------------------ point <-> voxel
+ * F.spvoxelize(feats, idx, counts)  (torchsparse_utils.py:20,23,54): out[idx[i]] += f[i]/counts[idx[i]] */
+int lt_voxelize_fwd(const float* feats, const int32_t* idx, const int32_t* counts, float* out, int64_t N,
+                    int32_t C, int64_t V, lt_stream_t stream);
+int lt_voxelize_bwd(const float* gout, const int32_t* idx, const int32_t* counts, float* gfeats, int64_t N,
+                    int32_t C, int64_t V, lt_stream_t stream);
+/* F.calc_ti_weights(coords, idx_query, scale)  (torchsparse_utils.py:75): idx_query int64 [8,N] -> w [8,N] */
+int lt_calc_ti_weights(const float* pcoords, const int64_t* idx_query, int64_t N, int32_t scale, float* w,
+                       lt_stream_t stream);
+/* F.spdevoxelize(feats, idx[N,8], w[N,8])  (torchsparse_utils.py:81,93) */
+int lt_devoxelize_fwd(const float* feats, const int32_t* idx, const float* w, float* out, int64_t N, int32_t C,
+                      int64_t V, lt_stream_t stream);
+int lt_devoxelize_bwd(const float* gout, const int32_t* idx, const float* w, float* gfeats, int64_t N, int32_t C,
+                      int64_t V, lt_stream_t stream);
+
+/* ------------------------------------------------------------------ ST-voxel aggregation (HR_Block / CR_Block)
+ * see latte/models/hr_module.py:135-331 and :344-420; declared in the second half of this header */
+#include "latte_hip_st.h"
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,84 @@
+"""ctypes binding of liblatte_hip.so (the C-ABI declared in include/latte_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing or a call fails, this raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblatte_hip.so")
+
+P = ctypes.c_void_p
+I64 = ctypes.c_int64
+I32 = ctypes.c_int32
+F32 = ctypes.c_float
+PI64 = ctypes.POINTER(ctypes.c_int64)
+
+# name -> (restype, argtypes); must list every symbol include/latte_hip.h declares
+SIGNATURES = {
+    "lt_last_error": (ctypes.c_char_p, []),
+    "lt_version": (ctypes.c_int, []),
+    "lt_sphash": (ctypes.c_int, [P, I64, P, I32, P, P]),
+    "lt_table_bytes": (I64, [I64]),
+    "lt_hash_build": (ctypes.c_int, [P, I64, P, I64, P]),
+    "lt_hash_query": (ctypes.c_int, [P, I64, P, I64, P, P]),
+    "lt_spcount": (ctypes.c_int, [P, I64, P, I64, P]),
+    "lt_unique_workspace_bytes": (I64, [I64]),
+    "lt_unique_sorted": (ctypes.c_int, [P, I64, I32, P, I64, P, P, P, PI64, P]),
+    "lt_pack_xyz_keys": (ctypes.c_int, [P, I64, P, P]),
+    "lt_downsample_workspace_bytes": (I64, [I64]),
+    "lt_downsample_coords": (ctypes.c_int, [P, I64, I32, P, I64, P, PI64, P]),
+    "lt_kmap_workspace_bytes": (I64, [I64]),
+    "lt_kmap_build": (ctypes.c_int, [P, I64, P, I64, P, I32, P, I64, P, P]),
+    "lt_kmap_pairs_workspace_bytes": (I64, [I64, I64]),
+    "lt_kmap_pairs": (ctypes.c_int, [P, I32, I64, P, I64, P, P, PI64, P]),
+    "lt_kmap_reverse": (ctypes.c_int, [P, I32, I64, I64, P, P]),
+    "lt_spconv_packed_floats": (I64, [I32, I32, I32]),
+    "lt_spconv_pack_weights": (ctypes.c_int, [P, I32, I32, I32, I32, P, P]),
+    "lt_spconv_fwd": (ctypes.c_int, [P, P, P, P, P, I64, I64, I32, I32, I32, P]),
+    "lt_bn_workspace_bytes": (I64, [I64, I32]),
+    "lt_bn_stats": (ctypes.c_int, [P, I64, I32, P, I64, P, P, P]),
+    "lt_bn_apply": (ctypes.c_int, [P, P, P, P, P, F32, P, I32, P, I64, I32, P]),
+    "lt_bn_bwd_reduce": (ctypes.c_int, [P, P, P, P, P, F32, I32, I64, I32, P, I64, P, P, P]),
+    "lt_bn_bwd_apply": (ctypes.c_int, [P, P, P, P, P, P, F32, I32, P, P, P, P, I64, I32, P]),
+    "lt_voxelize_fwd": (ctypes.c_int, [P, P, P, P, I64, I32, I64, P]),
+    "lt_voxelize_bwd": (ctypes.c_int, [P, P, P, P, I64, I32, I64, P]),
+    "lt_calc_ti_weights": (ctypes.c_int, [P, P, I64, I32, P, P]),
+    "lt_devoxelize_fwd": (ctypes.c_int, [P, P, P, P, I64, I32, I64, P]),
+    "lt_devoxelize_bwd": (ctypes.c_int, [P, P, P, P, I64, I32, I64, P]),
+}
+
+_lib = None
+
+
+class LatteHipError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """Load liblatte_hip.so (fails loudly when it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LatteHipError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(make -C latte_amd/csrc). There is no CPU fallback for the product path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so is stale
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def call(name: str, *args) -> None:
+    """Call an int-returning entry point and raise with lt_last_error() on failure."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        msg = lib.lt_last_error()
+        raise LatteHipError(f"{name} failed (rc={rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,87 @@
+// Shared host-side helpers for liblatte_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#define LT_OK 0
+#define LT_ERR_ARG (-1)
+#define LT_ERR_HIP (-2)
+#define LT_ERR_WORKSPACE (-3)
+#define LT_ERR_RANGE (-4)
+
+// thread-local message returned by lt_last_error()
+void lt_set_error(const char* fmt, ...);
+
+#define LT_CHECK_HIP(expr)                                                          \
+  do {                                                                              \
+    hipError_t _e = (expr);                                                         \
+    if (_e != hipSuccess) {                                                         \
+      lt_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+      return LT_ERR_HIP;                                                            \
+    }                                                                               \
+  } while (0)
+
+#define LT_REQUIRE(cond, code, ...)   \
+  do {                                \
+    if (!(cond)) {                    \
+      lt_set_error(__VA_ARGS__);      \
+      return (code);                  \
+    }                                 \
+  } while (0)
+
+#define LT_LAUNCH_CHECK() LT_CHECK_HIP(hipGetLastError())
+
+static inline int64_t lt_align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+static inline int lt_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+// grid for a memory-bound grid-stride kernel: enough blocks to fill 256 CUs x 8, never 0
+static inline int lt_grid(int64_t work_items, int block) {
+  int64_t g = (work_items + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > 2048 * 4) g = 2048 * 4;
+  return (int)g;
+}
+
+// bump allocator over a caller-provided workspace (256-B aligned pieces)
+struct LtArena {
+  char* base;
+  int64_t size;
+  int64_t off;
+  LtArena(void* p, int64_t n) : base((char*)p), size(n), off(0) {}
+  void* take(int64_t bytes) {
+    int64_t o = lt_align_up(off, 256);
+    if (o + bytes > size) return nullptr;
+    off = o + bytes;
+    return base + o;
+  }
+};
+
+static inline int64_t lt_pow2_ge(int64_t x) {
+  int64_t p = 1;
+  while (p < x) p <<= 1;
+  return p;
+}
+
+// ---- device helpers -------------------------------------------------------
+#define LT_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
+
+__device__ __forceinline__ uint64_t lt_fnv1a4(int x, int y, int z, int b) {
+  // torchsparse v1.4.0 hash kernel semantics (reference call sites
+  // latte/models/torchsparse_utils.py:15,40,45,68,73): 64-bit FNV-1a over the four int32,
+  // folded to 60 bits.
+  uint64_t h = 14695981039346656037ull;
+  h ^= (uint32_t)x; h *= 1099511628211ull;
+  h ^= (uint32_t)y; h *= 1099511628211ull;
+  h ^= (uint32_t)z; h *= 1099511628211ull;
+  h ^= (uint32_t)b; h *= 1099511628211ull;
+  return (h >> 60) ^ (h & 0xFFFFFFFFFFFFFFFull);
+}
+
+__device__ __forceinline__ uint32_t lt_slot_mix(uint64_t k) {
+  // murmur3 finalizer: spreads table slots independently of how the key was formed
+  k ^= k >> 33; k *= 0xff51afd7ed558ccdull;
+  k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull;
+  k ^= k >> 33;
+  return (uint32_t)k;
+}

@@ -1,0 +1,235 @@
+// Kernel-map construction for spnn.Conv3d (torchsparse v1.4.0 conv3d internals; reference call sites
+// latte/models/basic_blocks.py:17,34,51,58,68 and latte/models/spvcnn.py:30,32).
+//
+// The product format is the dense neighbour table results[K,Vout] (row of the input voxel or -1): the
+// output-stationary conv kernel consumes it directly, so no (in,out) pair list, no nonzero(), and no
+// device->host copy of nbsizes sits on the hot path.  lt_kmap_pairs() materialises torchsparse's
+// (nbmaps, nbsizes) from the table on demand (API compatibility + bit-exact parity tests).
+#include "common.h"
+#include "table.h"
+#include "../../include/latte_hip.h"
+#include <cstring>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
+#include <limits.h>
+
+// ---------------------------------------------------------------- spdownsample
+// key = (b | x | y | z), 16 bits each, xyz biased by 32768 so that unsigned key order == (b,x,y,z) order
+__device__ __forceinline__ int floordiv(int a, int s) {
+  int q = a / s;
+  if ((a % s != 0) && ((a < 0) != (s < 0))) --q;
+  return q;
+}
+
+__global__ void k_downsample_keys(const int* __restrict__ coords, int64_t V, int s, int64_t* __restrict__ keys,
+                                  int* __restrict__ bad) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < V; i += (int64_t)gridDim.x * blockDim.x) {
+    const int4 c = reinterpret_cast<const int4*>(coords)[i];
+    const int x = floordiv(c.x, s) * s, y = floordiv(c.y, s) * s, z = floordiv(c.z, s) * s;
+    if (x < -32768 || x > 32767 || y < -32768 || y > 32767 || z < -32768 || z > 32767 || c.w < 0 || c.w > 32767)
+      *bad = 1;
+    keys[i] = ((int64_t)(c.w & 0x7FFF) << 48) | ((int64_t)((x + 32768) & 0xFFFF) << 32) |
+              ((int64_t)((y + 32768) & 0xFFFF) << 16) | (int64_t)((z + 32768) & 0xFFFF);
+  }
+}
+
+__global__ void k_unpack_bxyz(const int64_t* __restrict__ keys, int64_t V, int* __restrict__ coords) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < V; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint64_t k = (uint64_t)keys[i];
+    int4 c;
+    c.w = (int)(k >> 48);
+    c.x = (int)((k >> 32) & 0xFFFF) - 32768;
+    c.y = (int)((k >> 16) & 0xFFFF) - 32768;
+    c.z = (int)(k & 0xFFFF) - 32768;
+    reinterpret_cast<int4*>(coords)[i] = c;
+  }
+}
+
+extern "C" int64_t lt_downsample_workspace_bytes(int64_t V) {
+  if (V < 1) V = 1;
+  return lt_unique_workspace_bytes(V) + 2 * lt_align_up(V * 8, 256) + 512;
+}
+
+extern "C" int lt_downsample_coords(const int32_t* coords, int64_t V, int32_t sample_stride, void* ws,
+                                    int64_t ws_bytes, int32_t* out_coords, int64_t* count, hipStream_t stream) {
+  LT_REQUIRE(count, LT_ERR_ARG, "lt_downsample_coords: count pointer is null");
+  *count = 0;
+  LT_REQUIRE(V >= 0 && sample_stride >= 1, LT_ERR_ARG, "lt_downsample_coords: bad sizes");
+  if (V == 0) return LT_OK;
+  LT_REQUIRE(coords && ws && out_coords, LT_ERR_ARG, "lt_downsample_coords: null pointer");
+  LT_REQUIRE(ws_bytes >= lt_downsample_workspace_bytes(V), LT_ERR_WORKSPACE,
+             "lt_downsample_coords: workspace needs %lld bytes, got %lld",
+             (long long)lt_downsample_workspace_bytes(V), (long long)ws_bytes);
+  LtArena a(ws, ws_bytes);
+  int64_t* keys = (int64_t*)a.take(V * 8);
+  int64_t* ukeys = (int64_t*)a.take(V * 8);
+  int* bad = (int*)a.take(256);
+  const int64_t uws_bytes = lt_unique_workspace_bytes(V);
+  void* uws = a.take(uws_bytes);
+  LT_REQUIRE(keys && ukeys && bad && uws, LT_ERR_WORKSPACE, "lt_downsample_coords: arena exhausted");
+  LT_CHECK_HIP(hipMemsetAsync(bad, 0, 4, stream));
+  hipLaunchKernelGGL(k_downsample_keys, dim3(lt_grid(V, 256)), dim3(256), 0, stream, coords, V, sample_stride, keys,
+                     bad);
+  LT_LAUNCH_CHECK();
+  int64_t n_unique = 0;
+  int rc = lt_unique_sorted(keys, V, 63, uws, uws_bytes, ukeys, nullptr, nullptr, &n_unique, stream);
+  if (rc) return rc;
+  int bad_host = 0;
+  LT_CHECK_HIP(hipMemcpyAsync(&bad_host, bad, 4, hipMemcpyDeviceToHost, stream));
+  hipLaunchKernelGGL(k_unpack_bxyz, dim3(lt_grid(n_unique, 256)), dim3(256), 0, stream, ukeys, n_unique, out_coords);
+  LT_LAUNCH_CHECK();
+  LT_CHECK_HIP(hipStreamSynchronize(stream));
+  LT_REQUIRE(!bad_host, LT_ERR_RANGE,
+             "lt_downsample_coords: coordinate outside [-32768,32767] or batch index outside [0,32767]");
+  *count = n_unique;
+  return LT_OK;
+}
+
+// ---------------------------------------------------------------- neighbour table
+__global__ void k_kmap_insert(const int* __restrict__ coords, int64_t V, LtTable t) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < V; i += (int64_t)gridDim.x * blockDim.x) {
+    const int4 c = reinterpret_cast<const int4*>(coords)[i];
+    lt_table_insert_min(t, lt_fnv1a4(c.x, c.y, c.z, c.w), (int)i);
+  }
+}
+
+// one thread per (k, o); o fastest so the coords_out reads and the results writes are coalesced
+__global__ void k_kmap_query(const int* __restrict__ coords_out, int64_t Vout, const int* __restrict__ offsets, int K,
+                             LtTable t, int* __restrict__ results) {
+  const int64_t total = Vout * (int64_t)K;
+  for (int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(g / Vout);
+    const int64_t o = g - (int64_t)k * Vout;
+    const int4 c = reinterpret_cast<const int4*>(coords_out)[o];
+    const uint64_t h = lt_fnv1a4(c.x + offsets[3 * k], c.y + offsets[3 * k + 1], c.z + offsets[3 * k + 2], c.w);
+    const int s = lt_table_find(t, h);
+    results[g] = s < 0 ? -1 : t.vals[s];
+  }
+}
+
+extern "C" int64_t lt_kmap_workspace_bytes(int64_t Vin) { return lt_table_bytes_for(Vin) + 256; }
+
+extern "C" int lt_kmap_build(const int32_t* coords_in, int64_t Vin, const int32_t* coords_out, int64_t Vout,
+                             const int32_t* offsets, int32_t K, void* ws, int64_t ws_bytes, int32_t* results,
+                             hipStream_t stream) {
+  LT_REQUIRE(Vin >= 0 && Vout >= 0 && K >= 1, LT_ERR_ARG, "lt_kmap_build: bad sizes");
+  LT_REQUIRE(Vin < INT_MAX && Vout < INT_MAX, LT_ERR_RANGE, "lt_kmap_build: more than 2^31 voxels");
+  if (Vout == 0) return LT_OK;
+  LT_REQUIRE(coords_out && offsets && ws && results && (Vin == 0 || coords_in), LT_ERR_ARG,
+             "lt_kmap_build: null pointer");
+  LT_REQUIRE(ws_bytes >= lt_kmap_workspace_bytes(Vin), LT_ERR_WORKSPACE,
+             "lt_kmap_build: workspace needs %lld bytes, got %lld", (long long)lt_kmap_workspace_bytes(Vin),
+             (long long)ws_bytes);
+  LtTable t = lt_table_view(ws, Vin);
+  int rc = lt_table_clear(t, stream);
+  if (rc) return rc;
+  if (Vin > 0) {
+    hipLaunchKernelGGL(k_kmap_insert, dim3(lt_grid(Vin, 256)), dim3(256), 0, stream, coords_in, Vin, t);
+    LT_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(k_kmap_query, dim3(lt_grid(Vout * K, 256)), dim3(256), 0, stream, coords_out, Vout, offsets, K, t,
+                     results);
+  LT_LAUNCH_CHECK();
+  return LT_OK;
+}
+
+// ---------------------------------------------------------------- (nbmaps, nbsizes) in torchsparse order
+struct HitFlag {
+  __device__ int operator()(int r) const { return r >= 0 ? 1 : 0; }
+};
+
+__global__ void k_emit_pairs(const int* __restrict__ results, const int* __restrict__ pos, int K, int64_t Vout,
+                             int* __restrict__ nbmaps, int* __restrict__ nbsizes, int* __restrict__ total) {
+  const int64_t n = Vout * (int64_t)K;
+  for (int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; g < n; g += (int64_t)gridDim.x * blockDim.x) {
+    const int r = results[g];
+    const int p = pos[g];
+    const int64_t o = g % Vout;
+    if (r >= 0) {
+      nbmaps[2 * (int64_t)p] = r;
+      nbmaps[2 * (int64_t)p + 1] = (int)o;
+    }
+    if (o == Vout - 1) {  // last column of row k: close the row
+      const int k = (int)(g / Vout);
+      const int end = p + (r >= 0 ? 1 : 0);
+      const int begin = pos[(int64_t)k * Vout];
+      nbsizes[k] = end - begin;
+      if (k == K - 1) *total = end;
+    }
+  }
+}
+
+static int64_t scan_temp_bytes(int64_t n) {
+  size_t bytes = 0;
+  int* p = nullptr;
+  auto it = rocprim::make_transform_iterator((const int*)nullptr, HitFlag());
+  (void)rocprim::exclusive_scan(nullptr, bytes, it, p, 0, (size_t)(n > 0 ? n : 1), rocprim::plus<int>(), (hipStream_t)0);
+  return (int64_t)bytes;
+}
+
+extern "C" int64_t lt_kmap_pairs_workspace_bytes(int64_t K, int64_t Vout) {
+  const int64_t n = (K > 0 ? K : 1) * (Vout > 0 ? Vout : 1);
+  return lt_align_up(n * 4, 256) + lt_align_up(scan_temp_bytes(n), 256) + 1024;
+}
+
+extern "C" int lt_kmap_pairs(const int32_t* results, int32_t K, int64_t Vout, void* ws, int64_t ws_bytes,
+                             int32_t* nbmaps, int32_t* nbsizes, int64_t* M, hipStream_t stream) {
+  LT_REQUIRE(M, LT_ERR_ARG, "lt_kmap_pairs: M pointer is null");
+  *M = 0;
+  LT_REQUIRE(K >= 1 && Vout >= 0, LT_ERR_ARG, "lt_kmap_pairs: bad sizes");
+  LT_REQUIRE(nbsizes, LT_ERR_ARG, "lt_kmap_pairs: null pointer");
+  if (Vout == 0) {
+    LT_CHECK_HIP(hipMemsetAsync(nbsizes, 0, K * 4, stream));
+    return LT_OK;
+  }
+  const int64_t n = (int64_t)K * Vout;
+  LT_REQUIRE(n < INT_MAX, LT_ERR_RANGE, "lt_kmap_pairs: K*Vout exceeds int32");
+  LT_REQUIRE(results && ws && nbmaps, LT_ERR_ARG, "lt_kmap_pairs: null pointer");
+  LT_REQUIRE(ws_bytes >= lt_kmap_pairs_workspace_bytes(K, Vout), LT_ERR_WORKSPACE,
+             "lt_kmap_pairs: workspace needs %lld bytes, got %lld", (long long)lt_kmap_pairs_workspace_bytes(K, Vout),
+             (long long)ws_bytes);
+  LtArena a(ws, ws_bytes);
+  int* pos = (int*)a.take(n * 4);
+  int* total = (int*)a.take(256);
+  const int64_t tb = scan_temp_bytes(n);
+  void* tmp = a.take(tb);
+  LT_REQUIRE(pos && total && tmp, LT_ERR_WORKSPACE, "lt_kmap_pairs: arena exhausted");
+  size_t tbs = (size_t)tb;
+  auto it = rocprim::make_transform_iterator(results, HitFlag());
+  LT_CHECK_HIP(rocprim::exclusive_scan(tmp, tbs, it, pos, 0, (size_t)n, rocprim::plus<int>(), stream));
+  hipLaunchKernelGGL(k_emit_pairs, dim3(lt_grid(n, 256)), dim3(256), 0, stream, results, pos, K, Vout, nbmaps, nbsizes,
+                     total);
+  LT_LAUNCH_CHECK();
+  int total_host = 0;
+  LT_CHECK_HIP(hipMemcpyAsync(&total_host, total, 4, hipMemcpyDeviceToHost, stream));
+  LT_CHECK_HIP(hipStreamSynchronize(stream));
+  *M = total_host;
+  return LT_OK;
+}
+
+// ---------------------------------------------------------------- reverse table
+__global__ void k_kmap_reverse(const int* __restrict__ results, int K, int64_t Vout, int64_t Vin,
+                               int* __restrict__ rev) {
+  const int64_t n = Vout * (int64_t)K;
+  for (int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; g < n; g += (int64_t)gridDim.x * blockDim.x) {
+    const int r = results[g];
+    if (r >= 0 && r < Vin) {
+      const int k = (int)(g / Vout);
+      rev[(int64_t)k * Vin + r] = (int)(g - (int64_t)k * Vout);
+    }
+  }
+}
+
+extern "C" int lt_kmap_reverse(const int32_t* results, int32_t K, int64_t Vout, int64_t Vin, int32_t* rev,
+                               hipStream_t stream) {
+  LT_REQUIRE(K >= 1 && Vout >= 0 && Vin >= 0, LT_ERR_ARG, "lt_kmap_reverse: bad sizes");
+  if (Vin == 0) return LT_OK;
+  LT_REQUIRE(rev && (Vout == 0 || results), LT_ERR_ARG, "lt_kmap_reverse: null pointer");
+  LT_CHECK_HIP(hipMemsetAsync(rev, 0xFF, (int64_t)K * Vin * 4, stream));
+  if (Vout > 0) {
+    hipLaunchKernelGGL(k_kmap_reverse, dim3(lt_grid((int64_t)K * Vout, 256)), dim3(256), 0, stream, results, K, Vout,
+                       Vin, rev);
+    LT_LAUNCH_CHECK();
+  }
+  return LT_OK;
+}

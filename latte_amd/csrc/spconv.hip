@@ -1,0 +1,282 @@
+// Sparse 3-D convolution for gfx950: output-stationary gather -> fp32 MFMA -> plain store.
+//
+// Replaces spnn.Conv3d forward / backward-input of torchsparse v1.4.0 (gather -> cuBLAS GEMM -> scatter-add, one
+// round per kernel offset); reference call sites latte/models/basic_blocks.py:17,34,51,58,68 and
+// latte/models/spvcnn.py:30,32.
+//
+//   out[o,:] = sum_k in[nbr[k,o],:] @ Wk
+//
+// Mapping to CDNA4
+//  * a workgroup (4 waves) owns 64 output rows x (16*NT) output channels; each wave owns a 16-row strip and keeps
+//    its NT 16x16 accumulators (v_mfma_f32_16x16x4_f32, exact fp32 = fmaf chain) in registers for the whole K loop:
+//    every output row is written exactly once -> no scatter, no atomics, bitwise reproducible.
+//  * A operand (gathered input rows): lane (r=lane&15, q=lane>>4) loads 16 B of row nbr[k][row r] at channel
+//    16j+4q straight into VGPRs (4 lanes cover 64 contiguous bytes of a row); the 4 floats feed 4 consecutive
+//    MFMAs, i.e. the reduction index inside a 16-channel group is permuted (4q+t), and the weights are packed
+//    with the same permutation, so no LDS transpose of the gathered rows is needed.
+//  * B operand (Wk): packed once per call into MFMA-fragment order [k][j][nt][lane][t]; a workgroup stages
+//    JB x NT KiB of it per step through LDS with 16-B loads/stores and each lane reads its 4 t-values with one
+//    conflict-free ds_read_b128 (lane-linear image).
+//  * offsets with no neighbour in the 64-row tile are skipped for the whole workgroup, offsets with no neighbour
+//    in a wave's 16-row strip skip that wave's MFMAs (wave-uniform branch).
+#include "common.h"
+#include "../../include/latte_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define LT_TM 64        // output rows per workgroup
+#define LT_KMAX 32      // max kernel volume held in LDS (27 used)
+#define LT_JB 4         // 16-channel groups staged per step
+
+// ---------------------------------------------------------------- weight packing
+// vec layout  (Cin_e % 16 == 0): packed[(((k*J + j)*NTt + nt)*64 + lane)*4 + t] = E_k[16j + 4q + t][16nt + n]
+// scalar layout (otherwise)    : packed[((k*S + s)*NTt + nt)*64 + lane]          = E_k[4s + q][16nt + n]
+// with q = lane>>4, n = lane&15 and E_k = Wk (mode 0), Wk^T (mode 1), W(K-1-k)^T (mode 2).
+__global__ void k_pack_weights(const float* __restrict__ W, int K, int Cin, int Cout, int mode,
+                               float* __restrict__ packed) {
+  const int Ce_in = mode == 0 ? Cin : Cout;
+  const int Ce_out = mode == 0 ? Cout : Cin;
+  const int NTt = Ce_out / 16;
+  const bool vec = (Ce_in % 16) == 0;
+  const int64_t total = (int64_t)K * Ce_in * Ce_out;
+  for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = p;
+    int k, ci, co;
+    if (vec) {
+      const int t = (int)(r & 3); r >>= 2;
+      const int lane = (int)(r & 63); r >>= 6;
+      const int nt = (int)(r % NTt); r /= NTt;
+      const int J = Ce_in / 16;
+      const int j = (int)(r % J);
+      k = (int)(r / J);
+      ci = 16 * j + 4 * (lane >> 4) + t;
+      co = 16 * nt + (lane & 15);
+    } else {
+      const int lane = (int)(r & 63); r >>= 6;
+      const int nt = (int)(r % NTt); r /= NTt;
+      const int S = Ce_in / 4;
+      const int s = (int)(r % S);
+      k = (int)(r / S);
+      ci = 4 * s + (lane >> 4);
+      co = 16 * nt + (lane & 15);
+    }
+    float v;
+    if (mode == 0) v = W[((int64_t)k * Cin + ci) * Cout + co];
+    else {
+      const int ks = mode == 2 ? (K - 1 - k) : k;
+      v = W[((int64_t)ks * Cin + co) * Cout + ci];  // E[ci][co] = W[ks][co][ci]
+    }
+    packed[p] = v;
+  }
+}
+
+extern "C" int64_t lt_spconv_packed_floats(int32_t K, int32_t Cin, int32_t Cout) { return (int64_t)K * Cin * Cout; }
+
+extern "C" int lt_spconv_pack_weights(const float* W, int32_t K, int32_t Cin, int32_t Cout, int32_t mode,
+                                      float* packed, hipStream_t stream) {
+  LT_REQUIRE(W && packed, LT_ERR_ARG, "lt_spconv_pack_weights: null pointer");
+  LT_REQUIRE(K >= 1 && Cin >= 1 && Cout >= 1 && mode >= 0 && mode <= 2, LT_ERR_ARG, "lt_spconv_pack_weights: bad args");
+  const int Ce_in = mode == 0 ? Cin : Cout, Ce_out = mode == 0 ? Cout : Cin;
+  LT_REQUIRE(Ce_in % 4 == 0 && Ce_out % 16 == 0, LT_ERR_ARG,
+             "lt_spconv_pack_weights: effective Cin=%d must be a multiple of 4 and Cout=%d of 16", Ce_in, Ce_out);
+  const int64_t total = (int64_t)K * Cin * Cout;
+  hipLaunchKernelGGL(k_pack_weights, dim3(lt_grid(total, 256)), dim3(256), 0, stream, W, K, Cin, Cout, mode, packed);
+  LT_LAUNCH_CHECK();
+  return LT_OK;
+}
+
+// ---------------------------------------------------------------- forward kernel
+struct ConvArgs {
+  const float* in;
+  const float* packed;
+  const int* nbr;
+  const int* order;
+  float* out;
+  int Vin, Vout, Cin, Cout, K;
+};
+
+// shared prologue: row ids of the tile + neighbour table of the tile + per-offset row masks
+__device__ __forceinline__ void conv_load_tile(const ConvArgs& a, int* s_rows, int* s_nbr, unsigned long long* s_mask) {
+  const int tid = threadIdx.x;
+  const int64_t tile0 = (int64_t)blockIdx.x * LT_TM;
+  if (tid < LT_TM) {
+    const int64_t slot = tile0 + tid;
+    int row = -1;
+    if (slot < a.Vout) row = a.order ? a.order[slot] : (int)slot;
+    s_rows[tid] = row;
+  }
+  __syncthreads();
+  for (int e = tid; e < a.K * LT_TM; e += blockDim.x) {
+    const int k = e / LT_TM, i = e % LT_TM;
+    const int row = s_rows[i];
+    int v = -1;
+    if (row >= 0) v = a.nbr[(int64_t)k * a.Vout + row];
+    if (v >= a.Vin) v = -1;  // defensive: never gather out of bounds
+    s_nbr[e] = v;
+  }
+  __syncthreads();
+  const int wave = tid >> 6, lane = tid & 63;
+  for (int k = wave; k < a.K; k += 4) {
+    const unsigned long long m = __ballot(s_nbr[k * LT_TM + lane] >= 0);
+    if (lane == 0) s_mask[k] = m;
+  }
+  __syncthreads();
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void k_spconv_vec(ConvArgs a) {
+  __shared__ __attribute__((aligned(16))) float s_w[LT_JB * NT * 64 * 4];
+  __shared__ int s_nbr[LT_KMAX * LT_TM];
+  __shared__ int s_rows[LT_TM];
+  __shared__ unsigned long long s_mask[LT_KMAX];
+
+  conv_load_tile(a, s_rows, s_nbr, s_mask);
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 15, q = lane >> 4;
+  const int J = a.Cin / 16;
+  const int NTt = a.Cout / 16;
+  const int nt0 = blockIdx.y * NT;
+
+  f32x4 acc[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int k = 0; k < a.K; ++k) {
+    const unsigned long long m = s_mask[k];
+    if (m == 0ull) continue;  // workgroup-uniform
+    const bool wave_active = ((m >> (16 * wave)) & 0xFFFFull) != 0ull;
+    const int src = s_nbr[k * LT_TM + 16 * wave + r];
+    const float* src_row = a.in + (int64_t)(src < 0 ? 0 : src) * a.Cin + 4 * q;
+    for (int j0 = 0; j0 < J; j0 += LT_JB) {
+      const int jb = (J - j0) < LT_JB ? (J - j0) : LT_JB;
+      __syncthreads();  // previous step's readers are done with s_w
+      // stage jb slabs of NT KiB: slab (k, j0+jj) starts at float4 index ((k*J + j0+jj)*NTt + nt0)*64
+      const int n4 = jb * NT * 64;
+      for (int e = tid; e < n4; e += 256) {
+        const int jj = e / (NT * 64), rem = e - jj * (NT * 64);
+        const f32x4 v = reinterpret_cast<const f32x4*>(a.packed)[((int64_t)(k * J + j0 + jj) * NTt + nt0) * 64 + rem];
+        reinterpret_cast<f32x4*>(s_w)[e] = v;
+      }
+      // gather this step's A fragments (issued before the barrier: overlaps the staging)
+      f32x4 av[LT_JB];
+#pragma unroll
+      for (int jj = 0; jj < LT_JB; ++jj) {
+        av[jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (wave_active && jj < jb && src >= 0) av[jj] = *reinterpret_cast<const f32x4*>(src_row + 16 * (j0 + jj));
+      }
+      __syncthreads();
+      if (wave_active) {
+#pragma unroll
+        for (int jj = 0; jj < LT_JB; ++jj) {
+          if (jj < jb) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+              const f32x4 b = reinterpret_cast<const f32x4*>(s_w)[(jj * NT + n) * 64 + lane];
+              acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[jj].x, b.x, acc[n], 0, 0, 0);
+              acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[jj].y, b.y, acc[n], 0, 0, 0);
+              acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[jj].z, b.z, acc[n], 0, 0, 0);
+              acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[jj].w, b.w, acc[n], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+  }
+  // epilogue: C/D layout col = lane&15, row = 4*(lane>>4) + reg
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    const int row = s_rows[16 * wave + 4 * q + reg];
+    if (row >= 0) {
+      float* o = a.out + (int64_t)row * a.Cout + 16 * nt0 + r;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) o[16 * n] = acc[n][reg];
+    }
+  }
+}
+
+// small-Cin variant (Cin % 16 != 0, e.g. the 4-channel stem): one dword of A per MFMA, all of Wk staged at once
+template <int NT>
+__global__ __launch_bounds__(256) void k_spconv_scalar(ConvArgs a) {
+  __shared__ float s_w[3 * NT * 64];  // S <= 3 (Cin <= 12)
+  __shared__ int s_nbr[LT_KMAX * LT_TM];
+  __shared__ int s_rows[LT_TM];
+  __shared__ unsigned long long s_mask[LT_KMAX];
+
+  conv_load_tile(a, s_rows, s_nbr, s_mask);
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 15, q = lane >> 4;
+  const int S = a.Cin / 4;
+  const int NTt = a.Cout / 16;
+  const int nt0 = blockIdx.y * NT;
+
+  f32x4 acc[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int k = 0; k < a.K; ++k) {
+    const unsigned long long m = s_mask[k];
+    if (m == 0ull) continue;
+    const bool wave_active = ((m >> (16 * wave)) & 0xFFFFull) != 0ull;
+    const int src = s_nbr[k * LT_TM + 16 * wave + r];
+    __syncthreads();
+    for (int e = tid; e < S * NT * 64; e += 256) {
+      const int s = e / (NT * 64), rem = e - s * (NT * 64);
+      s_w[e] = a.packed[((int64_t)(k * S + s) * NTt + nt0) * 64 + rem];
+    }
+    float av[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+      if (wave_active && s < S && src >= 0) av[s] = a.in[(int64_t)src * a.Cin + 4 * s + q];
+    __syncthreads();
+    if (wave_active) {
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        if (s < S) {
+#pragma unroll
+          for (int n = 0; n < NT; ++n)
+            acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], s_w[(s * NT + n) * 64 + lane], acc[n], 0, 0, 0);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    const int row = s_rows[16 * wave + 4 * q + reg];
+    if (row >= 0) {
+      float* o = a.out + (int64_t)row * a.Cout + 16 * nt0 + r;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) o[16 * n] = acc[n][reg];
+    }
+  }
+}
+
+template <int NT>
+static int launch_conv(const ConvArgs& a, hipStream_t stream) {
+  dim3 grid(lt_cdiv(a.Vout, LT_TM), a.Cout / (16 * NT));
+  if (a.Cin % 16 == 0) hipLaunchKernelGGL(k_spconv_vec<NT>, grid, dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL(k_spconv_scalar<NT>, grid, dim3(256), 0, stream, a);
+  LT_LAUNCH_CHECK();
+  return LT_OK;
+}
+
+extern "C" int lt_spconv_fwd(const float* in, const float* packed, const int32_t* nbr, const int32_t* order, float* out,
+                             int64_t Vin, int64_t Vout, int32_t Cin, int32_t Cout, int32_t K, hipStream_t stream) {
+  LT_REQUIRE(Vin >= 0 && Vout >= 0 && Vin < INT32_MAX && Vout < INT32_MAX, LT_ERR_RANGE, "lt_spconv_fwd: bad row counts");
+  LT_REQUIRE(K >= 1 && K <= LT_KMAX, LT_ERR_ARG, "lt_spconv_fwd: kernel volume %d not in [1,%d]", K, LT_KMAX);
+  LT_REQUIRE(Cin >= 4 && Cin % 4 == 0 && (Cin % 16 == 0 || Cin <= 12), LT_ERR_ARG,
+             "lt_spconv_fwd: Cin=%d must be a multiple of 16, or 4/8/12", Cin);
+  LT_REQUIRE(Cout >= 16 && Cout % 16 == 0, LT_ERR_ARG, "lt_spconv_fwd: Cout=%d must be a multiple of 16", Cout);
+  if (Vout == 0) return LT_OK;
+  LT_REQUIRE(packed && nbr && out && (Vin == 0 || in), LT_ERR_ARG, "lt_spconv_fwd: null pointer");
+  ConvArgs a{in, packed, nbr, order, out, (int)Vin, (int)Vout, Cin, Cout, K};
+  const int ntt = Cout / 16;
+  // widest accumulator strip (<= 8 tiles = 128 channels) that divides the channel-tile count
+  if (ntt % 8 == 0) return launch_conv<8>(a, stream);
+  if (ntt % 6 == 0) return launch_conv<6>(a, stream);
+  if (ntt % 4 == 0) return launch_conv<4>(a, stream);
+  if (ntt % 3 == 0) return launch_conv<3>(a, stream);
+  if (ntt % 2 == 0) return launch_conv<2>(a, stream);
+  return launch_conv<1>(a, stream);
+}

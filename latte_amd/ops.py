@@ -1,0 +1,282 @@
+"""Tensor-level wrappers over the C-ABI (no autograd here; see functional.py).
+
+torch is plumbing only: it owns device memory and the stream; every op below is one or more calls into
+liblatte_hip.so.  All tensors must live on a CUDA(HIP) device -- there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _lib
+
+__all__ = [
+    "sphash", "HashTable", "sphashquery", "spcount", "unique_sorted", "pack_xyz_keys", "downsample_coords",
+    "kmap_build", "kmap_pairs", "kmap_reverse", "pack_weights", "spconv", "bn_stats", "bn_apply",
+    "bn_bwd", "voxelize_fwd", "voxelize_bwd", "calc_ti_weights", "devoxelize_fwd", "devoxelize_bwd",
+]
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t: torch.Tensor, dtype, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise _lib.LatteHipError(f"{name}: tensor must be on the GPU (no CPU fallback in the product path)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _ws(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+# ------------------------------------------------------------------ hashing
+def sphash(coords: torch.Tensor, offsets: torch.Tensor | None = None) -> torch.Tensor:
+    coords = _chk(coords, torch.int32, "sphash coords")
+    assert coords.dim() == 2 and coords.shape[1] == 4, coords.shape
+    n = coords.shape[0]
+    if offsets is None:
+        out = torch.empty(n, dtype=torch.int64, device=coords.device)
+        _lib.call("lt_sphash", _p(coords), n, None, 0, _p(out), _stream())
+        return out
+    offsets = _chk(offsets, torch.int32, "sphash offsets")
+    assert offsets.dim() == 2 and offsets.shape[1] == 3
+    K = offsets.shape[0]
+    out = torch.empty((K, n), dtype=torch.int64, device=coords.device)
+    _lib.call("lt_sphash", _p(coords), n, _p(offsets), K, _p(out), _stream())
+    return out
+
+
+class HashTable:
+    """Open-addressing table over int64 keys (value = row index)."""
+
+    def __init__(self, keys: torch.Tensor):
+        keys = _chk(keys.reshape(-1), torch.int64, "HashTable keys")
+        self.n = keys.numel()
+        lib = _lib.load()
+        self.mem = _ws(lib.lt_table_bytes(self.n), keys.device)
+        _lib.call("lt_hash_build", _p(keys), self.n, _p(self.mem), self.mem.numel(), _stream())
+
+    def query(self, queries: torch.Tensor) -> torch.Tensor:
+        q = _chk(queries, torch.int64, "HashTable queries")
+        out = torch.empty_like(q)
+        _lib.call("lt_hash_query", _p(q), q.numel(), _p(self.mem), self.n, _p(out), _stream())
+        return out
+
+
+def sphashquery(queries: torch.Tensor, references: torch.Tensor) -> torch.Tensor:
+    return HashTable(references).query(queries)
+
+
+def spcount(idx: torch.Tensor, num: int) -> torch.Tensor:
+    idx = _chk(idx.reshape(-1), torch.int32, "spcount idx")
+    out = torch.empty(int(num), dtype=torch.int32, device=idx.device)
+    _lib.call("lt_spcount", _p(idx), idx.numel(), _p(out), int(num), _stream())
+    return out
+
+
+def unique_sorted(keys: torch.Tensor, key_bits: int = 63, want_first=True, want_inverse=True):
+    """-> (sorted unique keys [V], first index [V] | None, inverse [N] | None)."""
+    keys = _chk(keys.reshape(-1), torch.int64, "unique_sorted keys")
+    n = keys.numel()
+    dev = keys.device
+    lib = _lib.load()
+    ws = _ws(lib.lt_unique_workspace_bytes(n), dev)
+    uk = torch.empty(n, dtype=torch.int64, device=dev)
+    first = torch.empty(n, dtype=torch.int64, device=dev) if want_first else None
+    inv = torch.empty(n, dtype=torch.int64, device=dev) if want_inverse else None
+    cnt = ctypes.c_int64(0)
+    _lib.call("lt_unique_sorted", _p(keys), n, int(key_bits), _p(ws), ws.numel(), _p(uk), _p(first), _p(inv),
+              ctypes.byref(cnt), _stream())
+    v = cnt.value
+    return uk[:v], (first[:v] if want_first else None), inv
+
+
+def pack_xyz_keys(coords3: torch.Tensor) -> torch.Tensor:
+    coords3 = _chk(coords3, torch.int32, "pack_xyz_keys coords")
+    assert coords3.dim() == 2 and coords3.shape[1] == 3
+    keys = torch.empty(coords3.shape[0], dtype=torch.int64, device=coords3.device)
+    _lib.call("lt_pack_xyz_keys", _p(coords3), coords3.shape[0], _p(keys), _stream())
+    return keys
+
+
+# ------------------------------------------------------------------ kernel maps
+def downsample_coords(coords: torch.Tensor, sample_stride: int) -> torch.Tensor:
+    coords = _chk(coords, torch.int32, "downsample coords")
+    V = coords.shape[0]
+    lib = _lib.load()
+    ws = _ws(lib.lt_downsample_workspace_bytes(V), coords.device)
+    out = torch.empty((V, 4), dtype=torch.int32, device=coords.device)
+    cnt = ctypes.c_int64(0)
+    _lib.call("lt_downsample_coords", _p(coords), V, int(sample_stride), _p(ws), ws.numel(), _p(out),
+              ctypes.byref(cnt), _stream())
+    return out[:cnt.value]
+
+
+def kmap_build(coords_in: torch.Tensor, coords_out: torch.Tensor, offsets: torch.Tensor) -> torch.Tensor:
+    coords_in = _chk(coords_in, torch.int32, "kmap coords_in")
+    coords_out = _chk(coords_out, torch.int32, "kmap coords_out")
+    offsets = _chk(offsets, torch.int32, "kmap offsets")
+    Vin, Vout, K = coords_in.shape[0], coords_out.shape[0], offsets.shape[0]
+    lib = _lib.load()
+    ws = _ws(lib.lt_kmap_workspace_bytes(Vin), coords_in.device)
+    res = torch.empty((K, Vout), dtype=torch.int32, device=coords_in.device)
+    _lib.call("lt_kmap_build", _p(coords_in), Vin, _p(coords_out), Vout, _p(offsets), K, _p(ws), ws.numel(),
+              _p(res), _stream())
+    return res
+
+
+def kmap_pairs(results: torch.Tensor):
+    results = _chk(results, torch.int32, "kmap_pairs results")
+    K, Vout = results.shape
+    lib = _lib.load()
+    ws = _ws(lib.lt_kmap_pairs_workspace_bytes(K, Vout), results.device)
+    nbmaps = torch.empty((max(K * Vout, 1), 2), dtype=torch.int32, device=results.device)
+    nbsizes = torch.empty(K, dtype=torch.int32, device=results.device)
+    m = ctypes.c_int64(0)
+    _lib.call("lt_kmap_pairs", _p(results), K, Vout, _p(ws), ws.numel(), _p(nbmaps), _p(nbsizes),
+              ctypes.byref(m), _stream())
+    return nbmaps[:m.value], nbsizes
+
+
+def kmap_reverse(results: torch.Tensor, Vin: int) -> torch.Tensor:
+    results = _chk(results, torch.int32, "kmap_reverse results")
+    K, Vout = results.shape
+    rev = torch.empty((K, int(Vin)), dtype=torch.int32, device=results.device)
+    _lib.call("lt_kmap_reverse", _p(results), K, Vout, int(Vin), _p(rev), _stream())
+    return rev
+
+
+# ------------------------------------------------------------------ sparse conv
+def pack_weights(weight: torch.Tensor, mode: int = 0) -> torch.Tensor:
+    """weight [K,Cin,Cout] (or [Cin,Cout]) fp32 -> MFMA-fragment order (see spconv.hip)."""
+    w = _chk(weight.detach(), torch.float32, "pack_weights")
+    if w.dim() == 2:
+        w = w.unsqueeze(0)
+    K, Cin, Cout = w.shape
+    packed = torch.empty(K * Cin * Cout, dtype=torch.float32, device=w.device)
+    _lib.call("lt_spconv_pack_weights", _p(w), K, Cin, Cout, int(mode), _p(packed), _stream())
+    return packed
+
+
+def spconv(feats: torch.Tensor, packed: torch.Tensor, nbr: torch.Tensor, cout: int,
+           order: torch.Tensor | None = None) -> torch.Tensor:
+    """out[o] = sum_k feats[nbr[k,o]] @ E_k with E packed by pack_weights; nbr int32 [K,Vout]."""
+    feats = _chk(feats, torch.float32, "spconv feats")
+    nbr = _chk(nbr, torch.int32, "spconv nbr")
+    packed = _chk(packed, torch.float32, "spconv packed")
+    Vin, Cin = feats.shape
+    K, Vout = nbr.shape
+    if packed.numel() != K * Cin * cout:
+        raise ValueError(f"spconv: packed weights have {packed.numel()} floats, expected {K}*{Cin}*{cout}")
+    if order is not None:
+        order = _chk(order, torch.int32, "spconv order")
+        assert order.numel() == Vout
+    out = torch.empty((Vout, cout), dtype=torch.float32, device=feats.device)
+    _lib.call("lt_spconv_fwd", _p(feats), _p(packed), _p(nbr), _p(order), _p(out), Vin, Vout, Cin, int(cout), K,
+              _stream())
+    return out
+
+
+# ------------------------------------------------------------------ batch norm
+def bn_stats(x: torch.Tensor):
+    x = _chk(x, torch.float32, "bn_stats x")
+    V, C = x.shape
+    lib = _lib.load()
+    ws = _ws(lib.lt_bn_workspace_bytes(V, C), x.device)
+    mean = torch.empty(C, dtype=torch.float32, device=x.device)
+    var = torch.empty(C, dtype=torch.float32, device=x.device)
+    _lib.call("lt_bn_stats", _p(x), V, C, _p(ws), ws.numel(), _p(mean), _p(var), _stream())
+    return mean, var
+
+
+def bn_apply(x, mean, var, gamma, beta, eps: float, residual=None, relu: bool = False, out=None):
+    x = _chk(x, torch.float32, "bn_apply x")
+    V, C = x.shape
+    y = torch.empty_like(x) if out is None else out
+    if residual is not None:
+        residual = _chk(residual, torch.float32, "bn_apply residual")
+        assert residual.shape == x.shape
+    _lib.call("lt_bn_apply", _p(x), _p(mean), _p(var), _p(_chk(gamma.detach(), torch.float32, "gamma")),
+              _p(_chk(beta.detach(), torch.float32, "beta")), float(eps), _p(residual), int(relu), _p(y), V, C,
+              _stream())
+    return y
+
+
+def bn_bwd(dy, x, y, mean, var, gamma, eps: float, relu: bool, need_dx=True, need_dres=False):
+    """-> (dx | None, dgamma, dbeta, dres | None)."""
+    dy = _chk(dy, torch.float32, "bn_bwd dy")
+    x = _chk(x, torch.float32, "bn_bwd x")
+    V, C = x.shape
+    lib = _lib.load()
+    ws = _ws(lib.lt_bn_workspace_bytes(V, C), x.device)
+    sum_g = torch.empty(C, dtype=torch.float32, device=x.device)
+    sum_gx = torch.empty(C, dtype=torch.float32, device=x.device)
+    yp = _p(y) if relu else None
+    _lib.call("lt_bn_bwd_reduce", _p(dy), _p(x), yp, _p(mean), _p(var), float(eps), int(relu), V, C, _p(ws),
+              ws.numel(), _p(sum_g), _p(sum_gx), _stream())
+    dx = torch.empty_like(x) if need_dx else None
+    dres = torch.empty_like(x) if need_dres else None
+    if need_dx or need_dres:
+        _lib.call("lt_bn_bwd_apply", _p(dy), _p(x), yp, _p(mean), _p(var),
+                  _p(_chk(gamma.detach(), torch.float32, "gamma")), float(eps), int(relu), _p(sum_g), _p(sum_gx),
+                  _p(dx), _p(dres), V, C, _stream())
+    return dx, sum_gx, sum_g, dres
+
+
+# ------------------------------------------------------------------ point <-> voxel
+def voxelize_fwd(feats, idx, counts):
+    feats = _chk(feats, torch.float32, "voxelize feats")
+    idx = _chk(idx, torch.int32, "voxelize idx")
+    counts = _chk(counts, torch.int32, "voxelize counts")
+    N, C = feats.shape
+    V = counts.numel()
+    out = torch.empty((V, C), dtype=torch.float32, device=feats.device)
+    _lib.call("lt_voxelize_fwd", _p(feats), _p(idx), _p(counts), _p(out), N, C, V, _stream())
+    return out
+
+
+def voxelize_bwd(gout, idx, counts, N: int):
+    gout = _chk(gout, torch.float32, "voxelize_bwd gout")
+    V, C = gout.shape
+    gf = torch.empty((N, C), dtype=torch.float32, device=gout.device)
+    _lib.call("lt_voxelize_bwd", _p(gout), _p(idx), _p(counts), _p(gf), N, C, V, _stream())
+    return gf
+
+
+def calc_ti_weights(pcoords, idx_query, scale: int):
+    """pcoords fp32 [N,4]; idx_query int64 [8,N] -> fp32 [8,N]."""
+    pcoords = _chk(pcoords, torch.float32, "ti_weights coords")
+    idx_query = _chk(idx_query, torch.int64, "ti_weights idx_query")
+    assert pcoords.shape[1] == 4 and idx_query.shape[0] == 8
+    N = pcoords.shape[0]
+    w = torch.empty((8, N), dtype=torch.float32, device=pcoords.device)
+    _lib.call("lt_calc_ti_weights", _p(pcoords), _p(idx_query), N, int(scale), _p(w), _stream())
+    return w
+
+
+def devoxelize_fwd(feats, idx, w):
+    feats = _chk(feats, torch.float32, "devox feats")
+    idx = _chk(idx, torch.int32, "devox idx")
+    w = _chk(w, torch.float32, "devox w")
+    V, C = feats.shape
+    N = idx.shape[0]
+    out = torch.empty((N, C), dtype=torch.float32, device=feats.device)
+    _lib.call("lt_devoxelize_fwd", _p(feats), _p(idx), _p(w), _p(out), N, C, V, _stream())
+    return out
+
+
+def devoxelize_bwd(gout, idx, w, V: int):
+    gout = _chk(gout, torch.float32, "devox_bwd gout")
+    N, C = gout.shape
+    gf = torch.empty((V, C), dtype=torch.float32, device=gout.device)
+    _lib.call("lt_devoxelize_bwd", _p(gout), _p(idx), _p(w), _p(gf), N, C, V, _stream())
+    return gf

@@ -1,0 +1,229 @@
+"""GPU parity of the individual C-ABI ops against the CPU oracle (oracle/ts_ref.py).
+Integer / index results must be bit-exact; fp32 results within 1e-3 relative (north_star tolerance)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ts_ref
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-3  # north_star: features/logits within 1e-3 relative, fp32
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def rel_err(a, b):
+    a = a.double()
+    b = b.double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def test_sphash_matches_oracle(scans_small):
+    from latte_amd import ops
+    c = scans_small["coords"]
+    h = ops.sphash(dev(c)).cpu().numpy()
+    assert np.array_equal(h, ts_ref.sphash(c))
+    off = ts_ref.get_kernel_offsets(3, 1)
+    hk = ops.sphash(dev(c), dev(off)).cpu().numpy()
+    assert np.array_equal(hk, ts_ref.sphash(c, off))
+
+
+def test_sphashquery_and_count(scans_small):
+    from latte_amd import ops
+    c = scans_small["coords"]
+    refs = ts_ref.sphash(c)
+    off = ts_ref.get_kernel_offsets(2, 1)
+    q = ts_ref.sphash(c, off)
+    got = ops.sphashquery(dev(q), dev(refs)).cpu().numpy()
+    assert np.array_equal(got, ts_ref.sphashquery(q, refs))
+    idx = got[0].astype(np.int32)
+    cnt = ops.spcount(dev(idx), c.shape[0]).cpu().numpy()
+    assert np.array_equal(cnt, ts_ref.spcount(idx, c.shape[0]))
+
+
+@pytest.mark.parametrize("n,hi", [(1, 5), (1000, 50), (50000, 3000), (200000, 1 << 40)])
+def test_unique_sorted_matches_numpy(n, hi):
+    from latte_amd import ops
+    rng = np.random.default_rng(n)
+    keys = rng.integers(0, hi, size=n, dtype=np.int64)
+    u, first, inv = np.unique(keys, return_index=True, return_inverse=True)
+    gu, gf, gi = ops.unique_sorted(dev(keys))
+    assert np.array_equal(gu.cpu().numpy(), u)
+    assert np.array_equal(gf.cpu().numpy(), first)
+    assert np.array_equal(gi.cpu().numpy(), inv.reshape(-1))
+
+
+def test_downsample_matches_oracle(scans_small):
+    from latte_amd import ops
+    c = scans_small["coords"]
+    for ts in (1, 2, 4):
+        base = ts_ref.spdownsample(c, ts, 1) if ts > 1 else c
+        want = ts_ref.spdownsample(base, 2, ts)
+        got = ops.downsample_coords(dev(base), 2 * ts).cpu().numpy()
+        assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("ks,stride", [(3, 1), (2, 2)])
+def test_kernel_map_bit_exact(scans_small, ks, stride):
+    from latte_amd import ops
+    c = scans_small["coords"]
+    nbmaps, nbsizes, out_coords, res = ts_ref.build_kmap(c, 1, ks, stride)
+    off = ts_ref.get_kernel_offsets(ks, 1)
+    got = ops.kmap_build(dev(c), dev(out_coords), dev(off))
+    assert np.array_equal(got.cpu().numpy(), res.astype(np.int32))
+    gm, gs = ops.kmap_pairs(got)
+    assert np.array_equal(gs.cpu().numpy(), nbsizes)
+    assert np.array_equal(gm.cpu().numpy(), nbmaps)
+    # reverse table: rev[k, i] = o  <=>  res[k, o] = i
+    rev = ops.kmap_reverse(got, c.shape[0]).cpu().numpy()
+    kk, oo = np.nonzero(res != -1)
+    assert np.array_equal(rev[kk, res[kk, oo]], oo)
+    assert (rev != -1).sum() == kk.size
+
+
+@pytest.mark.parametrize("cin,cout", [(4, 32), (32, 32), (32, 64), (96, 96), (128, 96), (192, 128), (256, 256), (48, 48)])
+def test_spconv_forward_matches_oracle(scans_small, cin, cout):
+    from latte_amd import ops
+    c = scans_small["coords"]
+    nbmaps, nbsizes, out_coords, res = ts_ref.build_kmap(c, 1, 3, 1)
+    g = torch.Generator().manual_seed(cin * 1000 + cout)
+    feats = torch.randn(c.shape[0], cin, generator=g)
+    w = torch.randn(27, cin, cout, generator=g) / np.sqrt(27 * cin)
+    want = ts_ref.conv3d(feats, w, nbmaps, nbsizes, c.shape[0])
+    got = ops.spconv(feats.cuda(), ops.pack_weights(w.cuda(), 0), dev(res, torch.int32), cout).cpu()
+    assert rel_err(got, want) < 1e-5
+    assert torch.allclose(got, want, rtol=RTOL, atol=1e-4)
+
+
+def test_spconv_strided_transposed_and_backward_tables(scans_small):
+    from latte_amd import ops
+    c = scans_small["coords"]
+    nbmaps, nbsizes, out_coords, res = ts_ref.build_kmap(c, 1, 2, 2)
+    g = torch.Generator().manual_seed(7)
+    cin, cout = 32, 64
+    feats = torch.randn(c.shape[0], cin, generator=g)
+    w = torch.randn(8, cin, cout, generator=g) / np.sqrt(8 * cin)
+    want = ts_ref.conv3d(feats, w, nbmaps, nbsizes, out_coords.shape[0])
+    resd = dev(res, torch.int32)
+    got = ops.spconv(feats.cuda(), ops.pack_weights(w.cuda(), 0), resd, cout).cpu()
+    assert rel_err(got, want) < 1e-5
+    # transposed conv (coarse -> fine) through the reverse table
+    wt = torch.randn(8, cout, cin, generator=g) / np.sqrt(8 * cout)
+    coarse = torch.randn(out_coords.shape[0], cout, generator=g)
+    want_t = ts_ref.conv3d(coarse, wt, nbmaps, nbsizes, c.shape[0], transposed=True)
+    rev = ops.kmap_reverse(resd, c.shape[0])
+    got_t = ops.spconv(coarse.cuda(), ops.pack_weights(wt.cuda(), 0), rev, cin).cpu()
+    assert rel_err(got_t, want_t) < 1e-5
+    # backward-input of the strided conv == transposed conv with Wk^T (mode 1)
+    gout = torch.randn(out_coords.shape[0], cout, generator=g)
+    f = feats.clone().requires_grad_(True)
+    ts_ref.conv3d(f, w, nbmaps, nbsizes, out_coords.shape[0]).backward(gout)
+    gin = ops.spconv(gout.cuda(), ops.pack_weights(w.cuda(), 1), rev, cin).cpu()
+    assert rel_err(gin, f.grad) < 1e-5
+
+
+def test_spconv_submanifold_backward_mode2(scans_small):
+    from latte_amd import ops
+    c = scans_small["coords"]
+    nbmaps, nbsizes, _, res = ts_ref.build_kmap(c, 1, 3, 1)
+    g = torch.Generator().manual_seed(11)
+    cin, cout = 32, 96
+    feats = torch.randn(c.shape[0], cin, generator=g, requires_grad=True)
+    w = torch.randn(27, cin, cout, generator=g) / np.sqrt(27 * cin)
+    gout = torch.randn(c.shape[0], cout, generator=g)
+    ts_ref.conv3d(feats, w, nbmaps, nbsizes, c.shape[0]).backward(gout)
+    gin = ops.spconv(gout.cuda(), ops.pack_weights(w.cuda(), 2), dev(res, torch.int32), cin).cpu()
+    assert rel_err(gin, feats.grad) < 1e-5
+
+
+def test_spconv_order_permutation_is_result_invariant(scans_small):
+    from latte_amd import ops
+    c = scans_small["coords"]
+    _, _, _, res = ts_ref.build_kmap(c, 1, 3, 1)
+    g = torch.Generator().manual_seed(3)
+    feats = torch.randn(c.shape[0], 32, generator=g).cuda()
+    pw = ops.pack_weights((torch.randn(27, 32, 32, generator=g) / 30).cuda(), 0)
+    resd = dev(res, torch.int32)
+    a = ops.spconv(feats, pw, resd, 32)
+    perm = torch.randperm(c.shape[0], generator=g).to(torch.int32).cuda()
+    b = ops.spconv(feats, pw, resd, 32, order=perm)
+    assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("V,C", [(2, 32), (37, 32), (5000, 96), (20000, 256)])
+@pytest.mark.parametrize("relu,res", [(False, False), (True, False), (True, True)])
+def test_batchnorm_fwd_bwd_matches_torch(V, C, relu, res):
+    from latte_amd import ops
+    g = torch.Generator().manual_seed(V + C)
+    x = (torch.randn(V, C, generator=g) * 2 + 3).requires_grad_(True)
+    gamma = (torch.rand(C, generator=g) + 0.5).requires_grad_(True)
+    beta = torch.randn(C, generator=g).requires_grad_(True)
+    r = torch.randn(V, C, generator=g).requires_grad_(True) if res else None
+    eps = 1e-5
+    y = torch.nn.functional.batch_norm(x, None, None, gamma, beta, True, 0.0, eps)
+    if res:
+        y = y + r
+    if relu:
+        y = torch.relu(y)
+    dy = torch.randn(V, C, generator=g)
+    y.backward(dy)
+    xc = x.detach().cuda()
+    mean, var = ops.bn_stats(xc)
+    assert torch.allclose(mean.cpu(), x.detach().mean(0), rtol=1e-5, atol=1e-5)
+    assert torch.allclose(var.cpu(), x.detach().var(0, unbiased=False), rtol=1e-4, atol=1e-6)
+    yg = ops.bn_apply(xc, mean, var, gamma.detach().cuda(), beta.detach().cuda(), eps,
+                      residual=None if r is None else r.detach().cuda(), relu=relu)
+    assert torch.allclose(yg.cpu(), y.detach(), rtol=RTOL, atol=1e-4)
+    if V > 1:
+        dx, dgamma, dbeta, dres = ops.bn_bwd(dy.cuda(), xc, yg, mean, var, gamma.detach().cuda(), eps, relu,
+                                             need_dx=True, need_dres=res)
+        assert rel_err(dx.cpu(), x.grad) < 1e-4
+        assert rel_err(dgamma.cpu(), gamma.grad) < 1e-4
+        assert rel_err(dbeta.cpu(), beta.grad) < 1e-4
+        if res:
+            assert rel_err(dres.cpu(), r.grad) < 1e-6
+
+
+def test_voxelize_devoxelize_match_oracle(scans_small):
+    from latte_amd import ops
+    c = scans_small["coords"]
+    N = c.shape[0]
+    g = torch.Generator().manual_seed(5)
+    # stride-4 cells
+    cell = c.copy()
+    cell[:, :3] = cell[:, :3] // 4 * 4
+    vox = ts_ref.spdownsample(ts_ref.spdownsample(c, 2, 1), 2, 2)
+    idx = ts_ref.sphashquery(ts_ref.sphash(cell), ts_ref.sphash(vox))
+    assert (idx >= 0).all()
+    counts = ts_ref.spcount(idx.astype(np.int32), vox.shape[0])
+    feats = torch.randn(N, 32, generator=g, requires_grad=True)
+    want = ts_ref.spvoxelize(feats, torch.from_numpy(idx), torch.from_numpy(counts))
+    gout = torch.randn(vox.shape[0], 32, generator=g)
+    want.backward(gout)
+    idx_d, cnt_d = dev(idx, torch.int32), dev(counts)
+    got = ops.voxelize_fwd(feats.detach().cuda(), idx_d, cnt_d)
+    assert torch.allclose(got.cpu(), want.detach(), rtol=RTOL, atol=1e-5)
+    gf = ops.voxelize_bwd(gout.cuda(), idx_d, cnt_d, N)
+    assert torch.allclose(gf.cpu(), feats.grad, rtol=RTOL, atol=1e-6)
+    # trilinear devoxelize at stride 4
+    off = ts_ref.get_kernel_offsets(2, 4)
+    q = ts_ref.sphashquery(ts_ref.sphash(cell, off), ts_ref.sphash(vox))  # [8,N]
+    pc = torch.from_numpy(c.astype(np.float32))
+    w_want = ts_ref.calc_ti_weights(pc, torch.from_numpy(q), 4)
+    w_got = ops.calc_ti_weights(pc.cuda(), dev(q), 4)
+    assert torch.equal(w_got.cpu(), w_want)
+    vf = torch.randn(vox.shape[0], 64, generator=g, requires_grad=True)
+    idx8 = torch.from_numpy(q.T.copy())
+    w8 = w_want.t().contiguous()
+    want_p = ts_ref.spdevoxelize(vf, idx8, w8)
+    gp = torch.randn(N, 64, generator=g)
+    want_p.backward(gp)
+    got_p = ops.devoxelize_fwd(vf.detach().cuda(), idx8.int().cuda(), w8.cuda())
+    assert torch.allclose(got_p.cpu(), want_p.detach(), rtol=RTOL, atol=1e-5)
+    gvf = ops.devoxelize_bwd(gp.cuda(), idx8.int().cuda(), w8.cuda(), vox.shape[0])
+    assert torch.allclose(gvf.cpu(), vf.grad, rtol=RTOL, atol=1e-5)
