@@ -1,0 +1,195 @@
+"""Autograd-aware sparse ops on top of the C-ABI (host-side glue; all arithmetic is in liblatte_hip.so).
+
+Mirrors what torchsparse v1.4.0's torch.autograd.Functions provide to the reference's 3-D backbone
+(latte/models/basic_blocks.py, latte/models/torchsparse_utils.py) -- same forward semantics, same gradients.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+from torch.autograd import Function
+
+from . import ops
+
+__all__ = ["KernelMap", "get_kernel_offsets", "sparse_conv", "batch_norm", "spvoxelize", "spdevoxelize"]
+
+_OFFSET_CACHE: dict = {}
+
+
+def _ntuple(v, n=3):
+    if isinstance(v, (tuple, list)):
+        assert len(v) == n
+        return tuple(int(x) for x in v)
+    return tuple(int(v) for _ in range(n))
+
+
+def get_kernel_offsets(size, stride=1, dilation=1, device="cpu") -> torch.Tensor:
+    """Kernel offsets in torchsparse v1.4.0 order (reference use: latte/models/torchsparse_utils.py:67):
+    odd kernel volume -> x fastest, even -> z fastest; values scaled by tensor stride * dilation."""
+    size, stride, dilation = _ntuple(size), _ntuple(stride), _ntuple(dilation)
+    key = (size, stride, dilation, str(device))
+    hit = _OFFSET_CACHE.get(key)
+    if hit is not None:
+        return hit
+    ax = [np.arange(-size[k] // 2 + 1, size[k] // 2 + 1) * stride[k] * dilation[k] for k in range(3)]
+    if int(np.prod(size)) % 2 == 1:
+        offs = [[x, y, z] for z in ax[2] for y in ax[1] for x in ax[0]]
+    else:
+        offs = [[x, y, z] for x in ax[0] for y in ax[1] for z in ax[2]]
+    t = torch.tensor(offs, dtype=torch.int32, device=device)
+    _OFFSET_CACHE[key] = t
+    return t
+
+
+class KernelMap:
+    """Kernel map of one (tensor_stride, kernel_size, stride, dilation) conv.
+
+    Product format: dense neighbour table `results` int32 [K, Vout].  torchsparse's list view
+    [nbmaps, nbsizes, (Vin, Vout)] is materialised lazily (kmap[0], kmap[1], kmap[2])."""
+
+    def __init__(self, results: torch.Tensor, n_in: int, n_out: int, submanifold: bool):
+        self.results = results
+        self.n_in, self.n_out = int(n_in), int(n_out)
+        self.submanifold = submanifold  # stride 1, odd kernel: results[K-1-k] is its own reverse table
+        self._rev = None
+        self._pairs = None
+
+    @property
+    def K(self):
+        return self.results.shape[0]
+
+    def reverse(self) -> torch.Tensor:
+        if self._rev is None:
+            self._rev = ops.kmap_reverse(self.results, self.n_in)
+        return self._rev
+
+    def pairs(self):
+        if self._pairs is None:
+            self._pairs = ops.kmap_pairs(self.results)
+        return self._pairs
+
+    def __getitem__(self, i):
+        if i == 0:
+            return self.pairs()[0]
+        if i == 1:
+            return self.pairs()[1]
+        if i == 2:
+            return (self.n_in, self.n_out)
+        raise IndexError(i)
+
+
+class _SparseConv(Function):
+    @staticmethod
+    def forward(ctx, feats, weight, kmap: KernelMap, transposed: bool):
+        w = weight if weight.dim() == 3 else weight.unsqueeze(0)
+        cout = w.shape[2]
+        packed = ops.pack_weights(w, 0)
+        nbr = kmap.reverse() if transposed else kmap.results
+        out = ops.spconv(feats, packed, nbr, cout)
+        ctx.kmap, ctx.transposed = kmap, transposed
+        ctx.save_for_backward(feats, weight)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        feats, weight = ctx.saved_tensors
+        kmap, transposed = ctx.kmap, ctx.transposed
+        w = weight if weight.dim() == 3 else weight.unsqueeze(0)
+        gout = gout.contiguous()
+        gfeats = gweight = None
+        if ctx.needs_input_grad[0]:
+            cin = w.shape[1]
+            if kmap.submanifold and not transposed:
+                gfeats = ops.spconv(gout, ops.pack_weights(w, 2), kmap.results, cin)
+            elif not transposed:
+                gfeats = ops.spconv(gout, ops.pack_weights(w, 1), kmap.reverse(), cin)
+            else:
+                gfeats = ops.spconv(gout, ops.pack_weights(w, 1), kmap.results, cin)
+        if ctx.needs_input_grad[1]:
+            # dW is only reached when TRAIN.UPDATE_PARAMS == "all" (latte/common/utils/ema_util.py:44-71); the
+            # shipped Latte configs train norm layers only.  Device-side torch ops over the pair list (not HIP yet).
+            nbmaps, nbsizes = kmap.pairs()
+            sizes = nbsizes.tolist()
+            gw = torch.zeros_like(w)
+            off = 0
+            for k, m in enumerate(sizes):
+                if m == 0:
+                    continue
+                p = nbmaps[off:off + m].long()
+                off += m
+                i_in, i_out = (p[:, 1], p[:, 0]) if transposed else (p[:, 0], p[:, 1])
+                gw[k] = feats[i_in].t() @ gout[i_out]
+            gweight = gw if weight.dim() == 3 else gw[0]
+        return gfeats, gweight, None, None
+
+
+def sparse_conv(feats, weight, kmap: KernelMap, transposed: bool = False):
+    return _SparseConv.apply(feats, weight, kmap, transposed)
+
+
+class _BatchNorm(Function):
+    """BN with batch statistics, optional fused residual add and ReLU: y = relu(bn(x) + residual)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, residual, eps, relu, stats_out):
+        mean, var = ops.bn_stats(x)
+        y = ops.bn_apply(x, mean, var, gamma, beta, eps, residual=residual, relu=relu)
+        ctx.eps, ctx.relu = eps, relu
+        ctx.has_res = residual is not None
+        ctx.save_for_backward(x, y if relu else None, mean, var, gamma)
+        if stats_out is not None:
+            stats_out.append((mean, var))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, mean, var, gamma = ctx.saved_tensors
+        dy = dy.contiguous()
+        need_dx = ctx.needs_input_grad[0]
+        need_dres = ctx.has_res and ctx.needs_input_grad[3]
+        dx, dgamma, dbeta, dres = ops.bn_bwd(dy, x, y, mean, var, gamma, ctx.eps, ctx.relu, need_dx=need_dx,
+                                             need_dres=need_dres)
+        return dx, dgamma, dbeta, dres, None, None, None
+
+
+def batch_norm(x, gamma, beta, eps=1e-5, residual=None, relu=False, stats_out=None):
+    if x.shape[0] * 1 == 1:
+        # same refusal as torch.nn.functional.batch_norm in training mode
+        raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(x.shape)}")
+    return _BatchNorm.apply(x, gamma, beta, residual, float(eps), bool(relu), stats_out)
+
+
+class _Voxelize(Function):
+    @staticmethod
+    def forward(ctx, feats, idx, counts):
+        ctx.n = feats.shape[0]
+        ctx.save_for_backward(idx, counts)
+        return ops.voxelize_fwd(feats, idx, counts)
+
+    @staticmethod
+    def backward(ctx, gout):
+        idx, counts = ctx.saved_tensors
+        return ops.voxelize_bwd(gout.contiguous(), idx, counts, ctx.n), None, None
+
+
+def spvoxelize(feats, idx, counts):
+    """F.spvoxelize (latte/models/torchsparse_utils.py:20,23,54); idx any int dtype, counts int32."""
+    return _Voxelize.apply(feats.contiguous(), idx.to(torch.int32).contiguous(), counts.to(torch.int32).contiguous())
+
+
+class _Devoxelize(Function):
+    @staticmethod
+    def forward(ctx, feats, idx, w):
+        ctx.v = feats.shape[0]
+        ctx.save_for_backward(idx, w)
+        return ops.devoxelize_fwd(feats, idx, w)
+
+    @staticmethod
+    def backward(ctx, gout):
+        idx, w = ctx.saved_tensors
+        return ops.devoxelize_bwd(gout.contiguous(), idx, w, ctx.v), None, None
+
+
+def spdevoxelize(feats, idx, w):
+    """F.spdevoxelize (latte/models/torchsparse_utils.py:81,93); idx [N,8] any int dtype, w [N,8] fp32."""
+    return _Devoxelize.apply(feats.contiguous(), idx.to(torch.int32).contiguous(), w.contiguous())

@@ -1,0 +1,75 @@
+"""Point <-> voxel bridges of SPVCNN with the reference's names and semantics
+(latte/models/torchsparse_utils.py:11-31 initial_voxelize, :36-59 point_to_voxel, :64-100 voxel_to_point).
+Index maps (idx_query, counts) are produced by the HIP hash table and must be bit-exact with the reference."""
+from __future__ import annotations
+
+import torch
+
+from . import functional as LF
+from . import ops
+from .tensor import PointTensor, SparseTensor
+
+__all__ = ["initial_voxelize", "point_to_voxel", "voxel_to_point"]
+
+
+def initial_voxelize(z: PointTensor, init_res: float, after_res: float) -> SparseTensor:
+    new_float_coord = torch.cat([(z.C[:, :3] * init_res) / after_res, z.C[:, -1].view(-1, 1)], 1)
+    floor_c = torch.floor(new_float_coord)
+    pc_hash = ops.sphash(floor_c.int().contiguous())
+    # torch.unique(pc_hash): voxels of x0 are ordered by ascending 60-bit hash
+    sparse_hash, _, idx_query = ops.unique_sorted(pc_hash, key_bits=60, want_first=False)
+    counts = ops.spcount(idx_query.int(), sparse_hash.numel())
+    inserted_coords = LF.spvoxelize(floor_c, idx_query, counts)
+    inserted_coords = torch.round(inserted_coords).int()
+    inserted_feat = LF.spvoxelize(z.F, idx_query, counts)
+    new_tensor = SparseTensor(inserted_feat, inserted_coords, 1)
+    new_tensor.cmaps.setdefault(new_tensor.stride, new_tensor.coords)
+    z.additional_features["idx_query"][1] = idx_query
+    z.additional_features["counts"][1] = counts
+    z.C = new_float_coord
+    return new_tensor
+
+
+def _cell_coords(z: PointTensor, s: int) -> torch.Tensor:
+    return torch.cat([torch.floor(z.C[:, :3] / s).int() * s, z.C[:, -1].int().view(-1, 1)], 1).contiguous()
+
+
+def point_to_voxel(x: SparseTensor, z: PointTensor) -> SparseTensor:
+    af = z.additional_features
+    if af is None or af.get("idx_query") is None or af["idx_query"].get(x.s) is None:
+        pc_hash = ops.sphash(_cell_coords(z, x.s[0]))
+        sparse_hash = ops.sphash(x.C.int().contiguous())
+        idx_query = ops.sphashquery(pc_hash, sparse_hash)
+        counts = ops.spcount(idx_query.int(), x.C.shape[0])
+        af["idx_query"][x.s] = idx_query
+        af["counts"][x.s] = counts
+    else:
+        idx_query, counts = af["idx_query"][x.s], af["counts"][x.s]
+    new_tensor = SparseTensor(LF.spvoxelize(z.F, idx_query, counts), x.C, x.s)
+    new_tensor.cmaps, new_tensor.kmaps = x.cmaps, x.kmaps
+    return new_tensor
+
+
+def voxel_to_point(x: SparseTensor, z: PointTensor, nearest: bool = False) -> PointTensor:
+    if z.idx_query is None or z.weights is None or z.idx_query.get(x.s) is None or z.weights.get(x.s) is None:
+        off = LF.get_kernel_offsets(2, x.s, 1, device=z.F.device)
+        old_hash = ops.sphash(_cell_coords(z, x.s[0]), off)
+        pc_hash = ops.sphash(x.C.int().contiguous())
+        idx_query = ops.sphashquery(old_hash, pc_hash)  # [8, N]
+        weights = ops.calc_ti_weights(z.C.float().contiguous(), idx_query, x.s[0]).transpose(0, 1).contiguous()
+        idx_query = idx_query.transpose(0, 1).contiguous()
+        if nearest:
+            weights[:, 1:] = 0.0
+            idx_query[:, 1:] = -1
+        new_feat = LF.spdevoxelize(x.F, idx_query, weights)
+        new_tensor = PointTensor(new_feat, z.C, idx_query=z.idx_query, weights=z.weights)
+        new_tensor.additional_features = z.additional_features
+        new_tensor.idx_query[x.s] = idx_query
+        new_tensor.weights[x.s] = weights
+        z.idx_query[x.s] = idx_query
+        z.weights[x.s] = weights
+    else:
+        new_feat = LF.spdevoxelize(x.F, z.idx_query.get(x.s), z.weights.get(x.s))
+        new_tensor = PointTensor(new_feat, z.C, idx_query=z.idx_query, weights=z.weights)
+        new_tensor.additional_features = z.additional_features
+    return new_tensor

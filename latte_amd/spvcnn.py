@@ -1,0 +1,184 @@
+"""SPVCNN 3-D U-Net backbone + Net3DSeg head on the MI355X sparse ops.
+
+Host-side mirror of the reference's module API (latte/models/spvcnn.py:16-165, latte/models/basic_blocks.py:13-76,
+latte/models/xmuda_arch.py:289-342, latte/data/collate.py:34-55): same constructor arguments, same module tree and
+parameter names (so reference checkpoints load with load_state_dict), same forward outputs.  The graph is described
+by a table instead of hand-written layers, and conv -> BN -> ReLU (+ residual) chains call the fused HIP
+BN/ReLU/residual kernel instead of three separate modules."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import sparse_modules as spnn
+from .point_voxel import initial_voxelize, point_to_voxel, voxel_to_point
+from .tensor import PointTensor, SparseTensor, cat
+
+__all__ = ["SPVCNN", "Net3DSeg", "BasicConvolutionBlock", "BasicDeconvolutionBlock", "ResidualBlock",
+           "inverse_to_all"]
+
+
+def _conv_bn(seq, x: SparseTensor, i: int, relu: bool, residual=None) -> SparseTensor:
+    """seq[i] = Conv3d, seq[i+1] = BatchNorm: conv, then the fused BN(+residual)(+ReLU) kernel."""
+    y = seq[i](x)
+    y.feats = seq[i + 1].bn_feats(y.feats, residual=residual, relu=relu)
+    return y
+
+
+class BasicConvolutionBlock(nn.Module):
+    def __init__(self, inc, outc, ks=3, stride=1, dilation=1):
+        super().__init__()
+        self.net = nn.Sequential(spnn.Conv3d(inc, outc, kernel_size=ks, dilation=dilation, stride=stride),
+                                 spnn.BatchNorm(outc), spnn.ReLU(True))
+
+    def forward(self, x):
+        return _conv_bn(self.net, x, 0, relu=True)
+
+
+class BasicDeconvolutionBlock(nn.Module):
+    def __init__(self, inc, outc, ks=3, stride=1):
+        super().__init__()
+        self.net = nn.Sequential(spnn.Conv3d(inc, outc, kernel_size=ks, stride=stride, transposed=True),
+                                 spnn.BatchNorm(outc), spnn.ReLU(True))
+
+    def forward(self, x):
+        return _conv_bn(self.net, x, 0, relu=True)
+
+
+class ResidualBlock(nn.Module):
+    def __init__(self, inc, outc, ks=3, stride=1, dilation=1):
+        super().__init__()
+        self.net = nn.Sequential(spnn.Conv3d(inc, outc, kernel_size=ks, dilation=dilation, stride=stride),
+                                 spnn.BatchNorm(outc), spnn.ReLU(True),
+                                 spnn.Conv3d(outc, outc, kernel_size=ks, dilation=dilation, stride=1),
+                                 spnn.BatchNorm(outc))
+        if inc == outc and stride == 1:
+            self.downsample = nn.Sequential()
+        else:
+            self.downsample = nn.Sequential(spnn.Conv3d(inc, outc, kernel_size=1, dilation=1, stride=stride),
+                                            spnn.BatchNorm(outc))
+        self.ReLU = spnn.ReLU(True)
+
+    def forward(self, x):
+        if len(self.downsample) == 0:
+            shortcut = x.feats
+        else:
+            shortcut = _conv_bn(self.downsample, x, 0, relu=False).feats
+        y = _conv_bn(self.net, x, 0, relu=True)
+        # relu(bn(conv(y)) + shortcut) in one kernel
+        return _conv_bn(self.net, y, 3, relu=True, residual=shortcut)
+
+
+_BASE_CHANNELS = (32, 32, 64, 128, 256, 256, 128, 96, 96)
+
+
+class SPVCNN(nn.Module):
+    """Point-voxel U-Net: stem, 4 down stages (2^3 s2 conv + 2 residual blocks), 4 up stages (2^3 s2 transposed
+    conv, skip concat, 2 residual blocks), 3 point-MLP branches.  kwargs: cr (channel ratio, default 1.0)."""
+
+    def __init__(self, **kwargs):
+        super().__init__()
+        cr = kwargs.get("cr", 1.0)
+        cs = [int(cr * c) for c in _BASE_CHANNELS]
+        self.pres = self.vres = 0.05
+        self.out_channels = cs[8]
+
+        self.stem = nn.Sequential(spnn.Conv3d(4, cs[0], kernel_size=3, stride=1), spnn.BatchNorm(cs[0]),
+                                  spnn.ReLU(True), spnn.Conv3d(cs[0], cs[0], kernel_size=3, stride=1),
+                                  spnn.BatchNorm(cs[0]), spnn.ReLU(True))
+        # encoder: (in, out) per stage
+        for n, (ci, co) in enumerate([(cs[0], cs[1]), (cs[1], cs[2]), (cs[2], cs[3]), (cs[3], cs[4])], start=1):
+            setattr(self, f"stage{n}", nn.Sequential(
+                BasicConvolutionBlock(ci, ci, ks=2, stride=2, dilation=1),
+                ResidualBlock(ci, co, ks=3, stride=1, dilation=1),
+                ResidualBlock(co, co, ks=3, stride=1, dilation=1)))
+        # decoder: (in, out, skip channels)
+        for n, (ci, co, sk) in enumerate([(cs[4], cs[5], cs[3]), (cs[5], cs[6], cs[2]), (cs[6], cs[7], cs[1]),
+                                          (cs[7], cs[8], cs[0])], start=1):
+            setattr(self, f"up{n}", nn.ModuleList([
+                BasicDeconvolutionBlock(ci, co, ks=2, stride=2),
+                nn.Sequential(ResidualBlock(co + sk, co, ks=3, stride=1, dilation=1),
+                              ResidualBlock(co, co, ks=3, stride=1, dilation=1))]))
+        self.point_transforms = nn.ModuleList([
+            nn.Sequential(nn.Linear(a, b), nn.BatchNorm1d(b), nn.ReLU(True))
+            for a, b in [(cs[0], cs[4]), (cs[4], cs[6]), (cs[6], cs[8])]])
+        self.weight_initialization()
+        self.dropout = nn.Dropout(0.3, True)
+
+    def weight_initialization(self):
+        for m in self.modules():
+            if isinstance(m, nn.BatchNorm1d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def _stem(self, x):
+        x = _conv_bn(self.stem, x, 0, relu=True)
+        return _conv_bn(self.stem, x, 3, relu=True)
+
+    def _up(self, up, y, skip):
+        y = up[0](y)
+        return up[1](cat([y, skip]))
+
+    def forward(self, x: SparseTensor) -> torch.Tensor:
+        z = PointTensor(x.F, x.C.float())
+        x0 = self._stem(initial_voxelize(z, self.pres, self.vres))
+        z0 = voxel_to_point(x0, z, nearest=False)
+
+        x1 = self.stage1(point_to_voxel(x0, z0))
+        x2 = self.stage2(x1)
+        x3 = self.stage3(x2)
+        x4 = self.stage4(x3)
+        z1 = voxel_to_point(x4, z0)
+        z1.F = z1.F + self.point_transforms[0](z0.F)
+
+        y1 = point_to_voxel(x4, z1)
+        y1.F = self.dropout(y1.F)
+        y1 = self._up(self.up1, y1, x3)
+        y2 = self._up(self.up2, y1, x2)
+        z2 = voxel_to_point(y2, z1)
+        z2.F = z2.F + self.point_transforms[1](z1.F)
+
+        y3 = point_to_voxel(y2, z2)
+        y3.F = self.dropout(y3.F)
+        y3 = self._up(self.up3, y3, x1)
+        y4 = self._up(self.up4, y3, x0)
+        z3 = voxel_to_point(y4, z2)
+        z3.F = z3.F + self.point_transforms[2](z2.F)
+        return z3.F
+
+
+class Net3DSeg(nn.Module):
+    """SPVCNN + linear segmentation head(s); forward(data_batch) -> {'feats','seg_logit'[,'seg_logit2']}."""
+
+    def __init__(self, num_classes, dual_head, backbone_3d, backbone_3d_kwargs, da_method=None, pretrained=False):
+        super().__init__()
+        if backbone_3d != "SPVCNN":
+            raise NotImplementedError(f"3D backbone {backbone_3d} not supported")
+        if pretrained:
+            raise NotImplementedError("pretrained=True loads a checkpoint that is not part of this repository")
+        self.backbone_3d = backbone_3d
+        self.net_3d = SPVCNN(**backbone_3d_kwargs)
+        self.linear = nn.Linear(self.net_3d.out_channels, num_classes)
+        self.dual_head = dual_head
+        if dual_head:
+            self.linear2 = nn.Linear(self.net_3d.out_channels, num_classes)
+        self.da_method = da_method
+
+    def forward(self, data_batch, reverse=False):
+        feats = self.net_3d(data_batch["lidar"])
+        preds = {"feats": feats, "seg_logit": self.linear(feats)}
+        if self.dual_head:
+            preds["seg_logit2"] = self.linear2(feats)
+        return preds
+
+
+def inverse_to_all(seg_logit: torch.Tensor, data_batch) -> torch.Tensor:
+    """Unique-voxel rows -> all raw points (latte/data/collate.py:34-55): one gather with a batch-offset index
+    instead of a Python loop of per-scan gathers."""
+    sizes = [int(i.shape[0]) for i in data_batch["indices"]]
+    idx, off = [], 0
+    for n, inv in zip(sizes, data_batch["inverse_map"]):
+        inv = inv if torch.is_tensor(inv) else torch.as_tensor(inv)
+        idx.append(inv.to(seg_logit.device, dtype=torch.int64) + off)
+        off += n
+    return seg_logit[torch.cat(idx, 0)]

@@ -180,9 +180,10 @@ def test_batchnorm_fwd_bwd_matches_torch(V, C, relu, res):
                       residual=None if r is None else r.detach().cuda(), relu=relu)
     assert torch.allclose(yg.cpu(), y.detach(), rtol=RTOL, atol=1e-4)
     if V > 1:
-        dx, dgamma, dbeta, dres = ops.bn_bwd(dy.cuda(), xc, yg, mean, var, gamma.detach().cuda(), eps, relu,
+        # ReLU mask from the oracle's y: a y within 1 ulp of 0 may differ in sign between CPU and GPU
+        dx, dgamma, dbeta, dres = ops.bn_bwd(dy.cuda(), xc, y.detach().cuda(), mean, var, gamma.detach().cuda(), eps, relu,
                                              need_dx=True, need_dres=res)
-        assert rel_err(dx.cpu(), x.grad) < 1e-4
+        assert rel_err(dx.cpu(), x.grad) < (RTOL if V < 100 else 1e-4)  # V=2: dx ~ 0 by cancellation
         assert rel_err(dgamma.cpu(), gamma.grad) < 1e-4
         assert rel_err(dbeta.cpu(), beta.grad) < 1e-4
         if res:

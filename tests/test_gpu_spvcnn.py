@@ -1,0 +1,127 @@
+"""End-to-end parity of the 3-D backbone (SPVCNN + heads) on the HIP path against the CPU oracle
+(oracle/spvcnn_ref.py) with identical weights.  Index structures bit-exact, features/logits 1e-3 relative."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-3
+
+
+def rel_err(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def make_model(cr, num_classes=9, seed=1):
+    from latte_amd.spvcnn import Net3DSeg
+    torch.manual_seed(seed)
+    m = Net3DSeg(num_classes, True, "SPVCNN", {"cr": cr})
+    # non-trivial BN affine parameters so gradient/scale errors are visible
+    g = torch.Generator().manual_seed(seed + 1)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm1d):
+            mod.weight.data = 0.5 + torch.rand(mod.weight.shape, generator=g)
+            mod.bias.data = 0.2 * torch.randn(mod.bias.shape, generator=g)
+    m.train()
+    m.net_3d.dropout.p = 0.0
+    return m
+
+
+@pytest.mark.parametrize("cr", [0.5, 1.0])
+def test_spvcnn_forward_matches_oracle(scans_small, cr):
+    from latte_amd.tensor import SparseTensor
+    from oracle.spvcnn_ref import SPVCNNRef
+    m = make_model(cr)
+    ref = SPVCNNRef(m.state_dict())
+    coords, feats = scans_small["coords"], torch.from_numpy(scans_small["feats"])
+    with torch.no_grad():
+        want = ref(coords, feats)
+    mg = m.cuda()
+    lidar = SparseTensor(feats.cuda(), torch.from_numpy(coords).cuda(), 1)
+    with torch.no_grad():
+        got = mg({"lidar": lidar})
+    # bit-exact index structures: voxel coords per level, kernel maps, voxel<->point maps
+    cm = lidar_cmaps = got_cmaps = None
+    x0 = ref.traced["x0_coords"]
+    # cmaps live on the tensors created inside forward; rebuild them through the public functions
+    from latte_amd.point_voxel import initial_voxelize
+    from latte_amd.tensor import PointTensor
+    from latte_amd import sparse_modules as spnn
+    z = PointTensor(lidar.F, lidar.C.float())
+    t0 = initial_voxelize(z, 0.05, 0.05)
+    assert np.array_equal(t0.C.cpu().numpy(), x0)
+    assert np.array_equal(z.additional_features["idx_query"][1].cpu().numpy(), ref.traced["idx_query_1"])
+    t = t0
+    for lvl, name in zip((1, 2, 4, 8), ("x1", "x2", "x3", "x4")):
+        km3, _ = spnn.build_kernel_map(t, 3, 1, 1)
+        nb, ns, sizes, _oc = ref.traced["kmaps"][(lvl, 3, 1)]
+        assert np.array_equal(km3[0].cpu().numpy(), nb) and np.array_equal(km3[1].cpu().numpy(), ns)
+        km2, oc = spnn.build_kernel_map(t, 2, 2, 1)
+        nb, ns, sizes, want_oc = ref.traced["kmaps"][(lvl, 2, 2)]
+        assert np.array_equal(oc.cpu().numpy(), want_oc) and np.array_equal(oc.cpu().numpy(), ref.traced[name + "_coords"])
+        assert np.array_equal(km2[0].cpu().numpy(), nb) and np.array_equal(km2[1].cpu().numpy(), ns)
+        from latte_amd.tensor import SparseTensor as ST
+        nt = ST(torch.zeros(oc.shape[0], 4, device="cuda"), oc, 2 * lvl)
+        nt.cmaps, nt.kmaps = t.cmaps, t.kmaps
+        nt.cmaps[nt.stride] = oc
+        t = nt
+    for k in ("feats", "seg_logit", "seg_logit2"):
+        e = rel_err(got[k].cpu(), want[k])
+        assert e < 1e-4, (k, e)
+        assert torch.allclose(got[k].cpu(), want[k], rtol=RTOL, atol=1e-3 * float(want[k].abs().max()))
+
+
+def test_spvcnn_bn_gradients_match_oracle(scans_small):
+    from latte_amd.tensor import SparseTensor
+    from oracle.spvcnn_ref import SPVCNNRef
+    m = make_model(0.5)
+    sd = m.state_dict()
+    ref = SPVCNNRef(sd)
+    names = [f"{mn}.{pn}"[len("net_3d."):] for mn, mod in m.named_modules() if isinstance(mod, torch.nn.BatchNorm1d)
+             for pn, _ in mod.named_parameters()]
+    ref_params = ref.parameters_requiring_grad(names)
+    coords, feats = scans_small["coords"], torch.from_numpy(scans_small["feats"])
+    g = torch.Generator().manual_seed(0)
+    want = ref(coords, feats)
+    tgt = torch.randint(0, 9, (coords.shape[0],), generator=g)
+    loss_ref = torch.nn.functional.cross_entropy(want["seg_logit"], tgt) + want["seg_logit2"].square().mean()
+    loss_ref.backward()
+    # Latte trains norm layers only (latte/common/utils/ema_util.py:6-41)
+    mg = m.cuda()
+    mg.requires_grad_(False)
+    for mod in mg.modules():
+        if "norm" in type(mod).__name__.lower():
+            mod.requires_grad_(True)
+    lidar = SparseTensor(feats.cuda(), torch.from_numpy(coords).cuda(), 1)
+    got = mg({"lidar": lidar})
+    loss = torch.nn.functional.cross_entropy(got["seg_logit"], tgt.cuda()) + got["seg_logit2"].square().mean()
+    loss.backward()
+    assert abs(float(loss) - float(loss_ref)) < 1e-4 * abs(float(loss_ref))
+    errs = []
+    for n, pr in zip(names, ref_params):
+        pg = dict(mg.named_parameters())["net_3d." + n].grad
+        assert pg is not None, n
+        e = float((pg.cpu().double() - pr.grad.double()).norm() / (pr.grad.double().norm() + 1e-12))
+        errs.append((e, n, float(pr.grad.norm())))
+    errs.sort(reverse=True)
+    print("BN-grad rel errs (worst 8):", errs[:8], "median", errs[len(errs) // 2][0])
+    # Measured (scratch/dbg_flip.py): the forward differs from the oracle by ~1e-6, which flips the sign of 2-4 of
+    # the ~1e7 ReLU inputs (|x| < 1e-5).  ONE flipped element changes the gradient flowing through that layer by
+    # ~1/sqrt(rows*channels) = 2e-3 of its norm and every layer below inherits it, so whole-network gradient parity
+    # is bounded by flips, not by kernel arithmetic; each backward kernel alone matches to 1e-7 (test_gpu_ops.py).
+    assert errs[len(errs) // 2][0] < 1e-2
+    assert errs[0][0] < 3e-2, errs[0]
+
+
+def test_checkpoint_keys_follow_reference_names():
+    """reference checkpoints store torchsparse module names (net_3d.stem.0.kernel, ...):
+    latte/common/utils/checkpoint.py:39-87, latte/models/spvcnn.py:29-111."""
+    m = make_model(1.0)
+    sd = m.state_dict()
+    for k, shape in [("net_3d.stem.0.kernel", (27, 4, 32)), ("net_3d.stage1.0.net.0.kernel", (8, 32, 32)),
+                     ("net_3d.stage2.1.downsample.0.kernel", (32, 64)), ("net_3d.up1.0.net.0.kernel", (8, 256, 256)),
+                     ("net_3d.up1.1.0.net.0.kernel", (27, 384, 256)), ("net_3d.up4.1.1.net.3.kernel", (27, 96, 96)),
+                     ("net_3d.point_transforms.0.0.weight", (256, 32)), ("net_3d.stem.1.running_mean", (32,)),
+                     ("linear.weight", (9, 96)), ("linear2.bias", (9,))]:
+        assert k in sd and tuple(sd[k].shape) == shape, k
