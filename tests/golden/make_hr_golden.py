@@ -1,0 +1,132 @@
+"""Generates tests/golden/hr_*.npz by running the reference's OWN first-party ST-voxel code
+(latte/models/hr_module.py HR_Block / CR_Block, latte/models/losses.py prob_2_entropy,
+latte/data/utils/refine_pseudo_labels.py refine_ety / refine_pseudo_labels) on seeded synthetic inputs.
+
+Runs ONLY in the build container (needs /root/reference; it is never shipped to the GPU box and nothing in
+tests/ imports it).  The reference's absent third-party imports are stubbed exactly as SURVEY.md Appendix A
+describes: MagicMock for torchsparse/timm/open3d/..., and `torch_scatter.scatter` replaced by an index_add_
+based sum/mean (OUR restatement of the published semantics: rows = index.max()+1, count clamped >= 1).
+Only data (inputs + outputs) is stored; no reference source text.
+
+usage: PYTHONPATH=/root/reference PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_hr_golden.py
+"""
+import importlib
+import os
+import sys
+import types
+from unittest.mock import MagicMock
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+sys.path.insert(0, "/root/reference")
+
+
+def scatter(src, index, dim=0, out=None, dim_size=None, reduce="sum"):
+    n = int(index.max()) + 1 if dim_size is None else dim_size
+    o = torch.zeros((n,) + tuple(src.shape[1:]), dtype=src.dtype).index_add_(0, index, src)
+    if reduce == "mean":
+        cnt = torch.zeros(n, dtype=src.dtype).index_add_(0, index, torch.ones_like(index, dtype=src.dtype)).clamp_(min=1)
+        o = o / cnt.view((-1,) + (1,) * (src.dim() - 1))
+    return o
+
+
+ts = types.ModuleType("torch_scatter")
+ts.scatter = scatter
+sys.modules["torch_scatter"] = ts
+sys.modules["torch_scatter.scatter"] = types.ModuleType("torch_scatter.scatter")
+for m in ["torchsparse", "torchsparse.nn", "torchsparse.nn.functional", "torchsparse.nn.utils", "torchsparse.utils",
+          "torchsparse.utils.collate", "torchsparse.utils.quantize", "timm", "timm.models", "timm.models.layers",
+          "IPython", "open3d", "attr", "matplotlib", "matplotlib.pyplot"]:
+    try:
+        importlib.import_module(m)
+    except Exception:
+        sys.modules[m] = MagicMock()
+torch.Tensor.cuda = lambda self, *a, **k: self  # no GPU in the build container
+
+from latte.models.hr_module import HR_Block, CR_Block  # noqa: E402
+from latte.models.losses import prob_2_entropy  # noqa: E402
+from latte.data.utils.refine_pseudo_labels import refine_ety, refine_pseudo_labels  # noqa: E402
+
+from latte_amd import synth  # noqa: E402
+
+
+def make_case(name, n, B, C, W, vs, R, beams, full_360, seq_len, seed):
+    g = torch.Generator().manual_seed(seed)
+    pts, poses, scenes, ids, fov = [], [], [], [], []
+    for b in range(B):
+        p, _ = synth.make_scan(n, b, beams=beams, full_360=full_360)
+        pts.append(torch.from_numpy(p))
+        poses.append(torch.from_numpy(synth.make_pose(b % seq_len)))
+        scenes.append(f"scene-{100 + b // seq_len:04d}")
+        ids.append(b % seq_len)
+        keep = np.nonzero((p[:, 0] > 0) & (np.abs(p[:, 1]) < 0.8 * p[:, 0]))[0]
+        fov.append(torch.from_numpy(keep))
+    n_all = sum(p.shape[0] for p in pts)
+    n_fov = sum(f.shape[0] for f in fov)
+    logit_3d_student = (3 * torch.randn(n_all, C, generator=g)).requires_grad_(True)
+    logit_3d_teacher = 3 * torch.randn(n_all, C, generator=g)
+    logit_2d_student = (3 * torch.randn(n_fov, C, generator=g)).requires_grad_(True)
+    logit_2d_teacher = 3 * torch.randn(n_fov, C, generator=g)
+    pts_2d = [p[f] for p, f in zip(pts, fov)]
+    common = dict(pose=poses, scene_name=scenes, scan_ID=ids, img_indices=[torch.zeros(f.shape[0], 2) for f in fov])
+    b3 = lambda lg: dict(seg_logit=lg, ori_points=pts, **common)
+    b2 = lambda lg: dict(seg_logit=lg, ori_points=pts_2d, **common)
+    hr = HR_Block(temp_wd_size=W, max_range=R, voxel_size=vs, conf_perc=0.75)
+    cr = CR_Block(reduction="mean", conf_mask=True, ety_weight=True)
+    out = {}
+    for tag, (ab, at, hb, ht, a_lg) in {
+        "23": (b2(logit_2d_student), "2D", b3(logit_3d_teacher), "3D", logit_2d_student),
+        "32": (b3(logit_3d_student), "3D", b2(logit_2d_teacher), "2D", logit_3d_student),
+    }.items():
+        d = hr(ab, at, hb, ht)
+        # per-point entropies the caller injects (latte/tta/tools/latte.py:222-223,278,287)
+        ac_ety = prob_2_entropy(torch.softmax(ab["seg_logit"].detach(), 1)).sum(1)
+        tr_ety = prob_2_entropy(torch.softmax(hb["seg_logit"], 1)).sum(1)
+        d.update({"ac_pc_ety": ac_ety, "tr_pc_ety": tr_ety})
+        # CR_Block mutates ac/tr voxels in place (Q3): store copies first
+        for k in ("ac_logits", "ac_voxels", "tr_logits", "tr_voxels", "ac_p2v_indices", "tr_p2v_indices"):
+            for i, t in enumerate(d[k]):
+                out[f"{tag}_{k}_{i}"] = t.detach().clone().numpy()
+        out[f"{tag}_tr_conf_mask"] = d["tr_conf_mask"].numpy()
+        out[f"{tag}_hs_pc_ety"] = d["hs_pc_ety"].numpy()
+        out[f"{tag}_ac_pc_ety"] = ac_ety.numpy()
+        out[f"{tag}_tr_pc_ety"] = tr_ety.numpy()
+        loss = cr(d)
+        loss.backward()
+        out[f"{tag}_cr_loss"] = loss.detach().numpy()
+        out[f"{tag}_grad_anchor_logit"] = a_lg.grad.clone().numpy()
+        a_lg.grad = None
+    # refine_ety / refine_pseudo_labels / prob_2_entropy known-answer vectors
+    e = torch.rand(5000, generator=g)
+    lab = torch.randint(0, C, (5000,), generator=g)
+    out["refine_ety_in_ety"], out["refine_ety_in_label"] = e.numpy(), lab.numpy()
+    out["refine_ety_mask"] = refine_ety(e, lab, 0.75).numpy()
+    pr = torch.softmax(3 * torch.randn(5000, C, generator=g), 1)
+    out["p2e_in"], out["p2e_out"] = pr.numpy(), prob_2_entropy(pr).numpy()
+    mx, am = pr.max(1)
+    out["rpl_in_prob"], out["rpl_in_label"] = mx.numpy(), am.numpy()
+    out["rpl_out"] = refine_pseudo_labels(mx.clone(), am.clone()).numpy()
+    # inputs
+    for b in range(B):
+        out[f"in_points_{b}"] = pts[b].numpy()
+        out[f"in_pose_{b}"] = poses[b].numpy()
+        out[f"in_fov_{b}"] = fov[b].numpy()
+    out["in_scene"] = np.array(scenes)
+    out["in_scan_id"] = np.array(ids)
+    out["in_logit_3d_student"] = logit_3d_student.detach().numpy()
+    out["in_logit_3d_teacher"] = logit_3d_teacher.numpy()
+    out["in_logit_2d_student"] = logit_2d_student.detach().numpy()
+    out["in_logit_2d_teacher"] = logit_2d_teacher.numpy()
+    out["cfg"] = np.array([n, B, C, W, vs, R, 0.75], dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, f"hr_{name}.npz"), **out)
+    print(name, "saved;", {k: v.shape for k, v in out.items() if k.startswith("23_ac_logits")},
+          "loss23", out["23_cr_loss"], "loss32", out["32_cr_loss"])
+
+
+if __name__ == "__main__":
+    make_case("tiny", n=2048, B=3, C=5, W=3, vs=0.4, R=30, beams=16, full_360=False, seq_len=3, seed=0)
+    make_case("twoseq", n=4096, B=6, C=9, W=3, vs=0.2, R=40, beams=32, full_360=False, seq_len=3, seed=1)
+    make_case("w5_360", n=3072, B=5, C=16, W=5, vs=0.2, R=50, beams=32, full_360=True, seq_len=5, seed=2)
