@@ -1,4 +1,69 @@
-/* ST-voxel aggregation entry points (HR_Block / CR_Block); included by latte_hip.h */
+/* ST-voxel aggregation entry points (HR_Block / CR_Block of latte/models/hr_module.py); included by latte_hip.h.
+ *
+ * The reference loops in Python over the B anchors of a batch and, per anchor, goes host<->device six times
+ * (hr_module.py:188-299).  Here all anchors of a batch are one batched pipeline: every (anchor, window frame)
+ * pair is a "segment" of one flat element array, the anchor index sits in the top bits of the 64-bit voxel key,
+ * so ONE radix sort orders every voxel of every anchor and the per-voxel reductions are segmented reductions
+ * over sorted keys (no atomics; sums run in ascending point order like the reference's CPU index_add). */
 #ifndef LATTE_HIP_ST_H
 #define LATTE_HIP_ST_H
+
+/* F.softmax(logits, 1) and sum_c prob_2_entropy (hr_module.py:236-237,251; latte/models/losses.py:10-19):
+ * probs[p,:] = softmax(logits[p,:]); ety[p] = sum_c -p*log2(p+1e-30)/log2(C).  C <= 64. */
+int lt_softmax_entropy(const float* logits, int64_t P, int32_t C, float* probs, float* ety, lt_stream_t stream);
+/* backward of probs = softmax(logits): glogits = p * (g - sum_c g*p) */
+int lt_softmax_bwd(const float* probs, const float* gprobs, int64_t P, int32_t C, float* glogits, lt_stream_t stream);
+
+/* Pose transform (fp64) + range mask + fixed-origin voxel key for a flat element array (hr_module.py:210-233,
+ * sparse_quantize :73-97, ravel_hash :58-71 incl. the in-place shift Q1).
+ * Segment s covers elements [seg_out_start[s], seg_out_start[s+1]) = points[seg_src_start[s] ...] of one frame,
+ * belongs to anchor seg_anchor[s] and is transformed by the row-major 3x4 fp64 matrix seg_T + 12*s
+ * (seg_T == NULL: no transform, the fp32 range test of the anchor branch :227 is used).
+ * key = anchor<<48 | x<<32 | y<<16 | z with (x,y,z) = floor(p/voxel_size) - min_offset, or INT64_MAX when the point
+ * is outside max_range.  src[e] = index of the source point.  All seg_* arrays are DEVICE arrays. */
+int lt_st_keys(const float* points, const int64_t* seg_out_start, const int64_t* seg_src_start,
+               const int32_t* seg_anchor, const double* seg_T, int32_t S, int64_t E, double max_range,
+               double voxel_size, int32_t min_offset, int64_t* keys, int32_t* src, lt_stream_t stream);
+
+/* np.unique(keys, return_index, return_inverse) as a sort: one stable radix sort of (key, element) pairs, then
+ * segment heads.  Keys equal to INT64_MAX are "masked" and belong to no voxel.
+ * Outputs (device): sorted_elem[E]; inverse[E] (voxel id or -1); uniq_keys[cap E]; seg_start[cap E+1]
+ * (positions in sorted order, seg_start[V] = number of unmasked elements).  *V (HOST).  [sync] */
+int64_t lt_sort_segments_workspace_bytes(int64_t E);
+int lt_sort_segments(const int64_t* keys, int64_t E, int32_t key_bits, void* ws, int64_t ws_bytes,
+                     int32_t* sorted_elem, int32_t* inverse, int64_t* uniq_keys, int32_t* seg_start, int64_t* V,
+                     lt_stream_t stream);
+
+/* torch_scatter.scatter(src, index, dim=0, reduce) over sorted segments (hr_module.py:236,237,252):
+ * out[v,:] = reduce_{p in [seg_start[v], seg_start[v+1])} src[row(sorted_elem[p]), :], row(e) = src_index ? src_index[e] : e.
+ * mode 0 sum, 1 mean, 2 max (argmax[v,c] = element index, optional). */
+int lt_segment_reduce(const float* src, int32_t C, const int32_t* src_index, const int32_t* sorted_elem,
+                      const int32_t* seg_start, int64_t V, int32_t mode, float* out, int32_t* argmax,
+                      lt_stream_t stream);
+/* backward of mode 0/1 w.r.t. the ELEMENTS: gelem[e,:] = gout[inverse[e],:] / (mean ? count : 1), 0 when masked */
+int lt_segment_reduce_bwd(const float* gout, int32_t C, const int32_t* inverse, const int32_t* seg_start, int64_t E,
+                          int32_t mean, float* gelem, lt_stream_t stream);
+
+/* ST-voxel entropy written back to the points (hr_module.py:256-259,305-306):
+ * out[j] = mean over the anchors whose window holds point j's frame of voxel_ety[inverse[element of (anchor, j)]],
+ * 0 when no anchor sees the point in range.  frame_start[F+1]: point offsets of the hist frames; frame_seg[F*Wmax]:
+ * segments that contain frame f in ascending anchor order (-1 padded); seg_out_start as in lt_st_keys. */
+int lt_st_gather_back(const float* voxel_ety, const int32_t* inverse, const int64_t* frame_start, int32_t F,
+                      const int32_t* frame_seg, int32_t Wmax, const int64_t* seg_out_start, int64_t P, float* out,
+                      lt_stream_t stream);
+
+/* Voxel-set intersection of anchor and hist voxels (replaces the dense [Va,Vt] compare of hr_module.py:271-283):
+ * both key arrays are sorted ascending.  a_sel / t_sel (capacity min(Va,Vt)) receive the matched voxel ids in
+ * ascending order (k-th entries correspond); *M (HOST) = number of matches.  [sync] */
+int64_t lt_st_join_workspace_bytes(int64_t Va, int64_t Vt);
+int lt_st_join(const int64_t* a_keys, int64_t Va, const int64_t* t_keys, int64_t Vt, void* ws, int64_t ws_bytes,
+               int32_t* a_sel, int32_t* t_sel, int64_t* M, lt_stream_t stream);
+
+/* refine_ety (latte/data/utils/refine_pseudo_labels.py:33-53): per class c of label[0..n), thresh_c =
+ * torch.quantile(ety[label==c], q) (linear interpolation, fp32); mask[j] = !(ety[j] > thresh_label[j]).
+ * ety must be >= 0.  mask has n bytes. */
+int64_t lt_class_quantile_workspace_bytes(int64_t n);
+int lt_class_quantile_mask(const float* ety, const int32_t* label, int64_t n, int32_t num_classes, float q, void* ws,
+                           int64_t ws_bytes, uint8_t* mask, lt_stream_t stream);
+
 #endif

@@ -14,6 +14,7 @@ P = ctypes.c_void_p
 I64 = ctypes.c_int64
 I32 = ctypes.c_int32
 F32 = ctypes.c_float
+F64 = ctypes.c_double
 PI64 = ctypes.POINTER(ctypes.c_int64)
 
 # name -> (restype, argtypes); must list every symbol include/latte_hip.h declares
@@ -48,6 +49,19 @@ SIGNATURES = {
     "lt_calc_ti_weights": (ctypes.c_int, [P, P, I64, I32, P, P]),
     "lt_devoxelize_fwd": (ctypes.c_int, [P, P, P, P, I64, I32, I64, P]),
     "lt_devoxelize_bwd": (ctypes.c_int, [P, P, P, P, I64, I32, I64, P]),
+    # include/latte_hip_st.h
+    "lt_softmax_entropy": (ctypes.c_int, [P, I64, I32, P, P, P]),
+    "lt_softmax_bwd": (ctypes.c_int, [P, P, I64, I32, P, P]),
+    "lt_st_keys": (ctypes.c_int, [P, P, P, P, P, I32, I64, F64, F64, I32, P, P, P]),
+    "lt_sort_segments_workspace_bytes": (I64, [I64]),
+    "lt_sort_segments": (ctypes.c_int, [P, I64, I32, P, I64, P, P, P, P, PI64, P]),
+    "lt_segment_reduce": (ctypes.c_int, [P, I32, P, P, P, I64, I32, P, P, P]),
+    "lt_segment_reduce_bwd": (ctypes.c_int, [P, I32, P, P, I64, I32, P, P]),
+    "lt_st_gather_back": (ctypes.c_int, [P, P, P, I32, P, I32, P, I64, P, P]),
+    "lt_st_join_workspace_bytes": (I64, [I64, I64]),
+    "lt_st_join": (ctypes.c_int, [P, I64, P, I64, P, I64, P, P, PI64, P]),
+    "lt_class_quantile_workspace_bytes": (I64, [I64]),
+    "lt_class_quantile_mask": (ctypes.c_int, [P, P, I64, I32, F32, P, I64, P, P]),
 }
 
 _lib = None

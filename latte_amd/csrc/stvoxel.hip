@@ -1,0 +1,454 @@
+// Spatial-temporal voxel aggregation (HR_Block / refine_ety of the reference) as one batched GPU pipeline.
+// Reference: latte/models/hr_module.py:135-331, latte/models/losses.py:10-19,
+//            latte/data/utils/refine_pseudo_labels.py:33-53.  See include/latte_hip_st.h for the contract.
+//
+// Everything here is HBM-bound integer / fp32 streaming work: one lane per point or per (voxel, class), rows
+// contiguous across lanes, segmented reductions over radix-sorted voxel keys (atomic-free, summation order =
+// ascending point index, i.e. the order of the reference's CPU index_add).
+#include "common.h"
+#include "../../include/latte_hip.h"
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_select.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
+#include <limits.h>
+
+#define ST_MASKED 0x7FFFFFFFFFFFFFFFll
+
+// ---------------------------------------------------------------- softmax + entropy
+__global__ void k_softmax_entropy(const float* __restrict__ logits, int64_t P, int C, float* __restrict__ probs,
+                                  float* __restrict__ ety) {
+#pragma clang fp contract(off)
+  const float log2c = (float)log2((double)C);
+  for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < P; p += (int64_t)gridDim.x * blockDim.x) {
+    const float* row = logits + p * C;
+    float v[64];
+    float mx = -INFINITY;
+#pragma unroll 4
+    for (int c = 0; c < C; ++c) { v[c] = row[c]; mx = fmaxf(mx, v[c]); }
+    float sum = 0.f;
+    for (int c = 0; c < C; ++c) { v[c] = expf(v[c] - mx); sum += v[c]; }
+    float e = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float pr = v[c] / sum;
+      if (probs) probs[p * C + c] = pr;
+      e += (-(pr * log2f(pr + 1e-30f))) / log2c;
+    }
+    if (ety) ety[p] = e;
+  }
+}
+
+extern "C" int lt_softmax_entropy(const float* logits, int64_t P, int32_t C, float* probs, float* ety,
+                                  hipStream_t stream) {
+  LT_REQUIRE(P >= 0 && C >= 1 && C <= 64, LT_ERR_ARG, "lt_softmax_entropy: C=%d must be in [1,64]", C);
+  if (P == 0) return LT_OK;
+  LT_REQUIRE(logits && (probs || ety), LT_ERR_ARG, "lt_softmax_entropy: null pointer");
+  hipLaunchKernelGGL(k_softmax_entropy, dim3(lt_grid(P, 128)), dim3(128), 0, stream, logits, P, C, probs, ety);
+  LT_LAUNCH_CHECK();
+  return LT_OK;
+}
+
+__global__ void k_softmax_bwd(const float* __restrict__ probs, const float* __restrict__ g, int64_t P, int C,
+                              float* __restrict__ gl) {
+  for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < P; p += (int64_t)gridDim.x * blockDim.x) {
+    float dot = 0.f;
+    for (int c = 0; c < C; ++c) dot += g[p * C + c] * probs[p * C + c];
+    for (int c = 0; c < C; ++c) gl[p * C + c] = probs[p * C + c] * (g[p * C + c] - dot);
+  }
+}
+
+extern "C" int lt_softmax_bwd(const float* probs, const float* gprobs, int64_t P, int32_t C, float* glogits,
+                              hipStream_t stream) {
+  LT_REQUIRE(P >= 0 && C >= 1, LT_ERR_ARG, "lt_softmax_bwd: bad sizes");
+  if (P == 0) return LT_OK;
+  LT_REQUIRE(probs && gprobs && glogits, LT_ERR_ARG, "lt_softmax_bwd: null pointer");
+  hipLaunchKernelGGL(k_softmax_bwd, dim3(lt_grid(P, 128)), dim3(128), 0, stream, probs, gprobs, P, C, glogits);
+  LT_LAUNCH_CHECK();
+  return LT_OK;
+}
+
+// ---------------------------------------------------------------- transform + range + key
+__global__ void k_st_keys(const float* __restrict__ pts, const int64_t* __restrict__ seg_out, const int64_t* __restrict__ seg_src,
+                          const int* __restrict__ seg_anchor, const double* __restrict__ seg_T, int S, int64_t E,
+                          double R, double vs, int min_off, int64_t* __restrict__ keys, int* __restrict__ src) {
+#pragma clang fp contract(off)
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
+    // segment of e: largest s with seg_out[s] <= e  (S is small: <= anchors x window)
+    int lo = 0, hi = S - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (seg_out[mid] <= e) lo = mid; else hi = mid - 1;
+    }
+    const int s = lo;
+    const int64_t j = seg_src[s] + (e - seg_out[s]);
+    const float px = pts[3 * j], py = pts[3 * j + 1], pz = pts[3 * j + 2];
+    double x, y, z;
+    bool in_range;
+    if (seg_T) {
+      const double* T = seg_T + 12 * s;
+      // (T @ [p,1])[:3] in fp64, k ascending like a dgemm micro-kernel
+      x = T[0] * (double)px + T[1] * (double)py + T[2] * (double)pz + T[3];
+      y = T[4] * (double)px + T[5] * (double)py + T[6] * (double)pz + T[7];
+      z = T[8] * (double)px + T[9] * (double)py + T[10] * (double)pz + T[11];
+      in_range = sqrt(x * x + y * y + z * z) <= R;
+    } else {
+      x = (double)px; y = (double)py; z = (double)pz;
+      in_range = sqrtf(px * px + py * py + pz * pz) <= (float)R;  // fp32 norm of the anchor branch
+    }
+    int64_t key = ST_MASKED;
+    if (in_range) {
+      const int cx = (int)floor(x / vs) - min_off, cy = (int)floor(y / vs) - min_off, cz = (int)floor(z / vs) - min_off;
+      key = ((int64_t)seg_anchor[s] << 48) | ((int64_t)(cx & 0xFFFF) << 32) | ((int64_t)(cy & 0xFFFF) << 16) |
+            (int64_t)(cz & 0xFFFF);
+    }
+    keys[e] = key;
+    src[e] = (int)j;
+  }
+}
+
+extern "C" int lt_st_keys(const float* points, const int64_t* seg_out_start, const int64_t* seg_src_start,
+                          const int32_t* seg_anchor, const double* seg_T, int32_t S, int64_t E, double max_range,
+                          double voxel_size, int32_t min_offset, int64_t* keys, int32_t* src, hipStream_t stream) {
+  LT_REQUIRE(S >= 0 && E >= 0 && E < INT_MAX, LT_ERR_RANGE, "lt_st_keys: bad sizes");
+  if (E == 0) return LT_OK;
+  LT_REQUIRE(S >= 1 && points && seg_out_start && seg_src_start && seg_anchor && keys && src, LT_ERR_ARG,
+             "lt_st_keys: null pointer");
+  LT_REQUIRE(voxel_size > 0 && max_range > 0, LT_ERR_ARG, "lt_st_keys: voxel_size and max_range must be positive");
+  LT_REQUIRE(2.0 * max_range / voxel_size + 4.0 < 65536.0, LT_ERR_RANGE,
+             "lt_st_keys: max_range/voxel_size too large for 16-bit voxel coordinates");
+  hipLaunchKernelGGL(k_st_keys, dim3(lt_grid(E, 256)), dim3(256), 0, stream, points, seg_out_start, seg_src_start,
+                     seg_anchor, seg_T, S, E, max_range, voxel_size, min_offset, keys, src);
+  LT_LAUNCH_CHECK();
+  return LT_OK;
+}
+
+// ---------------------------------------------------------------- sort + segments
+struct HeadFlag {
+  const int64_t* k;
+  __device__ int operator()(int p) const {
+    const int64_t v = k[p];
+    return (v != ST_MASKED && (p == 0 || k[p - 1] != v)) ? 1 : 0;
+  }
+};
+
+__global__ void k_iota(int* __restrict__ a, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) a[i] = (int)i;
+}
+
+__global__ void k_emit_segments(const int64_t* __restrict__ skeys, const int* __restrict__ selem, const int* __restrict__ vid,
+                                int64_t E, int* __restrict__ inverse, int64_t* __restrict__ uniq, int* __restrict__ seg_start,
+                                int* __restrict__ counts /* [0]=V, [1]=n_valid */) {
+  for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < E; p += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t k = skeys[p];
+    const int e = selem[p];
+    if (k == ST_MASKED) {
+      inverse[e] = -1;
+      if (p == 0) { counts[0] = 0; counts[1] = 0; seg_start[0] = 0; }
+      continue;
+    }
+    const int v = vid[p] - 1;  // inclusive scan of head flags
+    inverse[e] = v;
+    if (p == 0 || skeys[p - 1] != k) { uniq[v] = k; seg_start[v] = (int)p; }
+    if (p == E - 1 || skeys[p + 1] == ST_MASKED) {
+      counts[0] = v + 1;
+      counts[1] = (int)(p + 1);
+      seg_start[v + 1] = (int)(p + 1);
+    }
+  }
+}
+
+static int64_t sortseg_sort_bytes(int64_t n) {
+  size_t b = 0;
+  int64_t* k = nullptr;
+  int* v = nullptr;
+  (void)rocprim::radix_sort_pairs(nullptr, b, k, k, v, v, (size_t)(n > 0 ? n : 1), 0, 64, (hipStream_t)0);
+  return (int64_t)b;
+}
+static int64_t sortseg_scan_bytes(int64_t n) {
+  size_t b = 0;
+  int* o = nullptr;
+  auto it = rocprim::make_transform_iterator(rocprim::counting_iterator<int>(0), HeadFlag{nullptr});
+  (void)rocprim::inclusive_scan(nullptr, b, it, o, (size_t)(n > 0 ? n : 1), rocprim::plus<int>(), (hipStream_t)0);
+  return (int64_t)b;
+}
+
+extern "C" int64_t lt_sort_segments_workspace_bytes(int64_t E) {
+  if (E < 1) E = 1;
+  return lt_align_up(E * 8, 256) + 3 * lt_align_up(E * 4, 256) + lt_align_up(sortseg_sort_bytes(E), 256) +
+         lt_align_up(sortseg_scan_bytes(E), 256) + 1024;
+}
+
+extern "C" int lt_sort_segments(const int64_t* keys, int64_t E, int32_t key_bits, void* ws, int64_t ws_bytes,
+                                int32_t* sorted_elem, int32_t* inverse, int64_t* uniq_keys, int32_t* seg_start,
+                                int64_t* V, hipStream_t stream) {
+  LT_REQUIRE(V, LT_ERR_ARG, "lt_sort_segments: V pointer is null");
+  *V = 0;
+  LT_REQUIRE(E >= 0 && E < INT_MAX, LT_ERR_RANGE, "lt_sort_segments: E out of range");
+  if (E == 0) return LT_OK;
+  LT_REQUIRE(keys && ws && sorted_elem && inverse && uniq_keys && seg_start, LT_ERR_ARG, "lt_sort_segments: null pointer");
+  LT_REQUIRE(ws_bytes >= lt_sort_segments_workspace_bytes(E), LT_ERR_WORKSPACE, "lt_sort_segments: workspace too small");
+  (void)key_bits;  // masked elements carry INT64_MAX, so all 63 bits take part in the sort
+  LtArena a(ws, ws_bytes);
+  int64_t* skeys = (int64_t*)a.take(E * 8);
+  int* iota = (int*)a.take(E * 4);
+  int* vid = (int*)a.take(E * 4);
+  int* counts = (int*)a.take(256);
+  const int64_t sb = sortseg_sort_bytes(E), cb = sortseg_scan_bytes(E);
+  void* stmp = a.take(sb);
+  void* ctmp = a.take(cb);
+  LT_REQUIRE(skeys && iota && vid && counts && stmp && ctmp, LT_ERR_WORKSPACE, "lt_sort_segments: arena exhausted");
+  hipLaunchKernelGGL(k_iota, dim3(lt_grid(E, 256)), dim3(256), 0, stream, iota, E);
+  LT_LAUNCH_CHECK();
+  size_t sbs = (size_t)sb, cbs = (size_t)cb;
+  // LSD radix sort is stable: equal keys keep ascending element order => segment head = first occurrence
+  LT_CHECK_HIP(rocprim::radix_sort_pairs(stmp, sbs, keys, skeys, iota, sorted_elem, (size_t)E, 0, 63, stream));
+  auto it = rocprim::make_transform_iterator(rocprim::counting_iterator<int>(0), HeadFlag{skeys});
+  LT_CHECK_HIP(rocprim::inclusive_scan(ctmp, cbs, it, vid, (size_t)E, rocprim::plus<int>(), stream));
+  hipLaunchKernelGGL(k_emit_segments, dim3(lt_grid(E, 256)), dim3(256), 0, stream, skeys, sorted_elem, vid, E, inverse,
+                     uniq_keys, seg_start, counts);
+  LT_LAUNCH_CHECK();
+  int host[2] = {0, 0};
+  LT_CHECK_HIP(hipMemcpyAsync(host, counts, 8, hipMemcpyDeviceToHost, stream));
+  LT_CHECK_HIP(hipStreamSynchronize(stream));
+  *V = host[0];
+  return LT_OK;
+}
+
+// ---------------------------------------------------------------- segmented reduce
+__global__ void k_segment_reduce(const float* __restrict__ src, int C, const int* __restrict__ src_index,
+                                 const int* __restrict__ selem, const int* __restrict__ seg_start, int64_t V, int mode,
+                                 float* __restrict__ out, int* __restrict__ argmax) {
+  const int64_t total = V * (int64_t)C;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t v = t / C;
+    const int c = (int)(t - v * C);
+    const int p0 = seg_start[v], p1 = seg_start[v + 1];
+    float acc = mode == 2 ? -INFINITY : 0.f;
+    int arg = -1;
+    for (int p = p0; p < p1; ++p) {
+      const int e = selem[p];
+      const int64_t row = src_index ? src_index[e] : e;
+      const float x = src[row * C + c];
+      if (mode == 2) { if (x > acc || arg < 0) { acc = x; arg = e; } }
+      else acc += x;
+    }
+    if (mode == 1) { const int n = p1 - p0; acc = acc / (float)(n < 1 ? 1 : n); }
+    if (mode == 2 && arg < 0) acc = 0.f;
+    out[t] = acc;
+    if (argmax) argmax[t] = arg;
+  }
+}
+
+extern "C" int lt_segment_reduce(const float* src, int32_t C, const int32_t* src_index, const int32_t* sorted_elem,
+                                 const int32_t* seg_start, int64_t V, int32_t mode, float* out, int32_t* argmax,
+                                 hipStream_t stream) {
+  LT_REQUIRE(V >= 0 && C >= 1 && mode >= 0 && mode <= 2, LT_ERR_ARG, "lt_segment_reduce: bad args");
+  if (V == 0) return LT_OK;
+  LT_REQUIRE(src && sorted_elem && seg_start && out, LT_ERR_ARG, "lt_segment_reduce: null pointer");
+  hipLaunchKernelGGL(k_segment_reduce, dim3(lt_grid(V * C, 256)), dim3(256), 0, stream, src, C, src_index, sorted_elem,
+                     seg_start, V, mode, out, argmax);
+  LT_LAUNCH_CHECK();
+  return LT_OK;
+}
+
+__global__ void k_segment_reduce_bwd(const float* __restrict__ g, int C, const int* __restrict__ inverse,
+                                     const int* __restrict__ seg_start, int64_t E, int mean, float* __restrict__ ge) {
+  const int64_t total = E * (int64_t)C;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = t / C;
+    const int c = (int)(t - e * C);
+    const int v = inverse[e];
+    float x = 0.f;
+    if (v >= 0) {
+      x = g[(int64_t)v * C + c];
+      if (mean) { const int n = seg_start[v + 1] - seg_start[v]; x = x / (float)(n < 1 ? 1 : n); }
+    }
+    ge[t] = x;
+  }
+}
+
+extern "C" int lt_segment_reduce_bwd(const float* gout, int32_t C, const int32_t* inverse, const int32_t* seg_start,
+                                     int64_t E, int32_t mean, float* gelem, hipStream_t stream) {
+  LT_REQUIRE(E >= 0 && C >= 1, LT_ERR_ARG, "lt_segment_reduce_bwd: bad args");
+  if (E == 0) return LT_OK;
+  LT_REQUIRE(gout && inverse && seg_start && gelem, LT_ERR_ARG, "lt_segment_reduce_bwd: null pointer");
+  hipLaunchKernelGGL(k_segment_reduce_bwd, dim3(lt_grid(E * C, 256)), dim3(256), 0, stream, gout, C, inverse, seg_start, E,
+                     mean, gelem);
+  LT_LAUNCH_CHECK();
+  return LT_OK;
+}
+
+// ---------------------------------------------------------------- ST entropy back to the points
+__global__ void k_st_gather_back(const float* __restrict__ vety, const int* __restrict__ inverse,
+                                 const int64_t* __restrict__ frame_start, int F, const int* __restrict__ frame_seg, int Wmax,
+                                 const int64_t* __restrict__ seg_out, int64_t P, float* __restrict__ out) {
+#pragma clang fp contract(off)
+  for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < P; j += (int64_t)gridDim.x * blockDim.x) {
+    int lo = 0, hi = F - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (frame_start[mid] <= j) lo = mid; else hi = mid - 1;
+    }
+    const int f = lo;
+    const int64_t local = j - frame_start[f];
+    float acc = 0.f;
+    int cnt = 0;
+    for (int w = 0; w < Wmax; ++w) {  // ascending anchor order == the reference's accumulation order
+      const int s = frame_seg[f * Wmax + w];
+      if (s < 0) break;
+      const int v = inverse[seg_out[s] + local];
+      if (v >= 0) { acc = acc + vety[v]; ++cnt; }
+    }
+    out[j] = cnt > 0 ? acc / (float)cnt : 0.f;
+  }
+}
+
+extern "C" int lt_st_gather_back(const float* voxel_ety, const int32_t* inverse, const int64_t* frame_start, int32_t F,
+                                 const int32_t* frame_seg, int32_t Wmax, const int64_t* seg_out_start, int64_t P,
+                                 float* out, hipStream_t stream) {
+  LT_REQUIRE(P >= 0 && F >= 1 && Wmax >= 1, LT_ERR_ARG, "lt_st_gather_back: bad sizes");
+  if (P == 0) return LT_OK;
+  LT_REQUIRE(inverse && frame_start && frame_seg && seg_out_start && out, LT_ERR_ARG, "lt_st_gather_back: null pointer");
+  hipLaunchKernelGGL(k_st_gather_back, dim3(lt_grid(P, 256)), dim3(256), 0, stream, voxel_ety, inverse, frame_start, F,
+                     frame_seg, Wmax, seg_out_start, P, out);
+  LT_LAUNCH_CHECK();
+  return LT_OK;
+}
+
+// ---------------------------------------------------------------- sorted-set join
+__global__ void k_join_probe(const int64_t* __restrict__ a, int64_t Va, const int64_t* __restrict__ t, int64_t Vt,
+                             int* __restrict__ a_hit, unsigned char* __restrict__ a_flag, unsigned char* __restrict__ t_flag) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < Va; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t key = a[i];
+    int64_t lo = 0, hi = Vt;  // lower_bound
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (t[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    const bool hit = lo < Vt && t[lo] == key;
+    a_hit[i] = hit ? (int)lo : -1;
+    a_flag[i] = hit ? 1 : 0;
+    if (hit) t_flag[lo] = 1;
+  }
+}
+
+static int64_t select_bytes(int64_t n) {
+  size_t b = 0;
+  unsigned char* f = nullptr;
+  int* o = nullptr;
+  (void)rocprim::select(nullptr, b, rocprim::counting_iterator<int>(0), f, o, o, (size_t)(n > 0 ? n : 1), (hipStream_t)0);
+  return (int64_t)b;
+}
+
+extern "C" int64_t lt_st_join_workspace_bytes(int64_t Va, int64_t Vt) {
+  const int64_t n = (Va > Vt ? Va : Vt) > 0 ? (Va > Vt ? Va : Vt) : 1;
+  return lt_align_up(Va > 0 ? Va * 4 : 4, 256) + lt_align_up(Va > 0 ? Va : 1, 256) + lt_align_up(Vt > 0 ? Vt : 1, 256) +
+         lt_align_up(select_bytes(n), 256) + 1024;
+}
+
+extern "C" int lt_st_join(const int64_t* a_keys, int64_t Va, const int64_t* t_keys, int64_t Vt, void* ws,
+                          int64_t ws_bytes, int32_t* a_sel, int32_t* t_sel, int64_t* M, hipStream_t stream) {
+  LT_REQUIRE(M, LT_ERR_ARG, "lt_st_join: M pointer is null");
+  *M = 0;
+  LT_REQUIRE(Va >= 0 && Vt >= 0 && Va < INT_MAX && Vt < INT_MAX, LT_ERR_RANGE, "lt_st_join: bad sizes");
+  if (Va == 0 || Vt == 0) return LT_OK;
+  LT_REQUIRE(a_keys && t_keys && ws && a_sel && t_sel, LT_ERR_ARG, "lt_st_join: null pointer");
+  LT_REQUIRE(ws_bytes >= lt_st_join_workspace_bytes(Va, Vt), LT_ERR_WORKSPACE, "lt_st_join: workspace too small");
+  LtArena a(ws, ws_bytes);
+  int* a_hit = (int*)a.take(Va * 4);
+  unsigned char* a_flag = (unsigned char*)a.take(Va);
+  unsigned char* t_flag = (unsigned char*)a.take(Vt);
+  int* cnt = (int*)a.take(256);
+  const int64_t sb = select_bytes(Va > Vt ? Va : Vt);
+  void* tmp = a.take(sb);
+  LT_REQUIRE(a_hit && a_flag && t_flag && cnt && tmp, LT_ERR_WORKSPACE, "lt_st_join: arena exhausted");
+  LT_CHECK_HIP(hipMemsetAsync(t_flag, 0, Vt, stream));
+  hipLaunchKernelGGL(k_join_probe, dim3(lt_grid(Va, 256)), dim3(256), 0, stream, a_keys, Va, t_keys, Vt, a_hit, a_flag,
+                     t_flag);
+  LT_LAUNCH_CHECK();
+  size_t sbs = (size_t)sb;
+  LT_CHECK_HIP(rocprim::select(tmp, sbs, rocprim::counting_iterator<int>(0), a_flag, a_sel, cnt, (size_t)Va, stream));
+  sbs = (size_t)sb;
+  LT_CHECK_HIP(rocprim::select(tmp, sbs, rocprim::counting_iterator<int>(0), t_flag, t_sel, cnt + 1, (size_t)Vt, stream));
+  int host[2] = {0, 0};
+  LT_CHECK_HIP(hipMemcpyAsync(host, cnt, 8, hipMemcpyDeviceToHost, stream));
+  LT_CHECK_HIP(hipStreamSynchronize(stream));
+  LT_REQUIRE(host[0] == host[1], LT_ERR_RANGE, "lt_st_join: duplicate keys in an input (%d vs %d matches)", host[0], host[1]);
+  *M = host[0];
+  return LT_OK;
+}
+
+// ---------------------------------------------------------------- class-wise quantile mask (refine_ety)
+__global__ void k_cq_keys(const float* __restrict__ ety, const int* __restrict__ label, int64_t n, int64_t* __restrict__ keys) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const unsigned int bits = __float_as_uint(ety[i] + 0.0f);  // ety >= 0: IEEE bit pattern is order-preserving
+    keys[i] = ((int64_t)(label[i] & 0xFFFF) << 32) | (int64_t)bits;
+  }
+}
+
+// one thread per class: segment of the class in the sorted keys -> torch.quantile threshold (fp32 arithmetic)
+__global__ void k_cq_thresh(const int64_t* __restrict__ skeys, int64_t n, int num_classes, float q, float* __restrict__ thresh) {
+#pragma clang fp contract(off)
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= num_classes) return;
+  const int64_t kb = (int64_t)c << 32, ke = (int64_t)(c + 1) << 32;
+  int64_t lo = 0, hi = n;
+  while (lo < hi) { const int64_t m = (lo + hi) >> 1; if (skeys[m] < kb) lo = m + 1; else hi = m; }
+  const int64_t b = lo;
+  hi = n;
+  while (lo < hi) { const int64_t m = (lo + hi) >> 1; if (skeys[m] < ke) lo = m + 1; else hi = m; }
+  const int64_t cnt = lo - b;
+  if (cnt == 0) { thresh[c] = INFINITY; return; }
+  const float rank = q * (float)(cnt - 1);
+  const float fl = floorf(rank), ce = ceilf(rank);
+  const float w = rank - fl;
+  const float a = __uint_as_float((unsigned int)(skeys[b + (int64_t)fl] & 0xFFFFFFFFll));
+  const float bb = __uint_as_float((unsigned int)(skeys[b + (int64_t)ce] & 0xFFFFFFFFll));
+  const float d = bb - a;
+  thresh[c] = (w < 0.5f) ? (a + w * d) : (bb - d * (1.0f - w));  // at::lerp
+}
+
+__global__ void k_cq_mask(const float* __restrict__ ety, const int* __restrict__ label, int64_t n, const float* __restrict__ thresh,
+                          unsigned char* __restrict__ mask) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    mask[i] = (ety[i] > thresh[label[i]]) ? 0 : 1;
+}
+
+static int64_t cq_sort_bytes(int64_t n) {
+  size_t b = 0;
+  int64_t* k = nullptr;
+  (void)rocprim::radix_sort_keys(nullptr, b, k, k, (size_t)(n > 0 ? n : 1), 0, 48, (hipStream_t)0);
+  return (int64_t)b;
+}
+
+extern "C" int64_t lt_class_quantile_workspace_bytes(int64_t n) {
+  if (n < 1) n = 1;
+  return 2 * lt_align_up(n * 8, 256) + lt_align_up(cq_sort_bytes(n), 256) + 65536 * 4 + 1024;
+}
+
+extern "C" int lt_class_quantile_mask(const float* ety, const int32_t* label, int64_t n, int32_t num_classes, float q,
+                                      void* ws, int64_t ws_bytes, uint8_t* mask, hipStream_t stream) {
+  LT_REQUIRE(n >= 0 && num_classes >= 1 && num_classes <= 65535, LT_ERR_ARG, "lt_class_quantile_mask: bad sizes");
+  LT_REQUIRE(q >= 0.f && q <= 1.f, LT_ERR_ARG, "lt_class_quantile_mask: q must be in [0,1]");
+  if (n == 0) return LT_OK;
+  LT_REQUIRE(ety && label && ws && mask, LT_ERR_ARG, "lt_class_quantile_mask: null pointer");
+  LT_REQUIRE(ws_bytes >= lt_class_quantile_workspace_bytes(n), LT_ERR_WORKSPACE, "lt_class_quantile_mask: workspace too small");
+  LtArena a(ws, ws_bytes);
+  int64_t* keys = (int64_t*)a.take(n * 8);
+  int64_t* skeys = (int64_t*)a.take(n * 8);
+  float* thresh = (float*)a.take((int64_t)num_classes * 4);
+  const int64_t sb = cq_sort_bytes(n);
+  void* tmp = a.take(sb);
+  LT_REQUIRE(keys && skeys && thresh && tmp, LT_ERR_WORKSPACE, "lt_class_quantile_mask: arena exhausted");
+  hipLaunchKernelGGL(k_cq_keys, dim3(lt_grid(n, 256)), dim3(256), 0, stream, ety, label, n, keys);
+  LT_LAUNCH_CHECK();
+  size_t sbs = (size_t)sb;
+  LT_CHECK_HIP(rocprim::radix_sort_keys(tmp, sbs, keys, skeys, (size_t)n, 0, 48, stream));
+  hipLaunchKernelGGL(k_cq_thresh, dim3(lt_cdiv(num_classes, 64)), dim3(64), 0, stream, skeys, n, num_classes, q, thresh);
+  LT_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_cq_mask, dim3(lt_grid(n, 256)), dim3(256), 0, stream, ety, label, n, thresh, mask);
+  LT_LAUNCH_CHECK();
+  return LT_OK;
+}

@@ -1,0 +1,243 @@
+"""ST-voxel aggregation modules with the reference's API (latte/models/hr_module.py:31-331 HR_Block,
+:334-420 CR_Block; built by build_model_hrcr, latte/models/build.py:43-53).
+
+Same constructor arguments, same forward signature, same 11-key output dict -- but ONE batched GPU pipeline over
+all anchors of the batch instead of a Python loop with host numpy in the middle:
+
+  pose transform (fp64) + range mask + voxel key      lt_st_keys            (anchor index in the key's top bits)
+  unique voxels / first index / inverse               lt_sort_segments      (one radix sort for all anchors)
+  softmax, point entropy                              lt_softmax_entropy
+  scatter-mean of probs and entropies per voxel       lt_segment_reduce     (segments of the sorted keys)
+  ST entropy back to the points                       lt_st_gather_back
+  anchor/hist voxel correspondence                    lt_st_join            (sorted-set join, not a [Va,Vt] matrix)
+  class-wise entropy quantile mask (refine_ety)       lt_class_quantile_mask
+
+Reference quirks Q1 (shifted voxel coords), Q2 (mask over all hist voxels, indexed by matched ones), Q4, Q6 are
+reproduced; see SURVEY.md §8a."""
+from __future__ import annotations
+
+import math
+from typing import Dict, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.autograd import Function
+
+from . import ops
+
+__all__ = ["HR_Block", "CR_Block", "prob_2_entropy", "refine_ety"]
+
+
+def prob_2_entropy(prob: torch.Tensor) -> torch.Tensor:
+    """latte/models/losses.py:10-19 (elementwise; the fused sum over classes lives in lt_softmax_entropy)."""
+    c = prob.shape[1]
+    return -torch.mul(prob, torch.log2(prob + 1e-30)) / np.log2(c)
+
+
+def refine_ety(ety: torch.Tensor, pseudo_label: torch.Tensor, conf_perc: float, num_classes: int | None = None):
+    """latte/data/utils/refine_pseudo_labels.py:33-53: per predicted class, mask entropies above the class quantile.
+    `ety` may be longer than `pseudo_label` (quirk Q2): only the first len(pseudo_label) entries can be masked."""
+    n = pseudo_label.numel()
+    mask = torch.ones(ety.numel(), dtype=torch.bool, device=ety.device)
+    if n == 0:
+        return mask
+    if num_classes is None:
+        num_classes = int(pseudo_label.max().item()) + 1
+    mask[:n] = ops.class_quantile_mask(ety[:n].detach().float().contiguous(), pseudo_label.to(torch.int32).contiguous(),
+                                       num_classes, float(conf_perc))
+    return mask
+
+
+class _VoxelMeanSoftmax(Function):
+    """voxel_probs = scatter_mean(softmax(logits)[in-range points], voxel id) with gradients to the logits."""
+
+    @staticmethod
+    def forward(ctx, logits, selem, inverse, seg_start):
+        probs, _ = ops.softmax_entropy(logits, want_ety=False)
+        out = ops.segment_reduce(probs, selem, seg_start, "mean")
+        ctx.save_for_backward(probs, inverse, seg_start)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        probs, inverse, seg_start = ctx.saved_tensors
+        ge = ops.segment_reduce_bwd(g.contiguous(), inverse, seg_start, True)
+        return ops.softmax_bwd(probs, ge), None, None, None
+
+
+def _scene_id(s) -> int:
+    s = str(s)
+    return int(s.split("-")[-1]) if "-" in s else int(s)
+
+
+def _decode_xyz(keys: torch.Tensor) -> torch.Tensor:
+    return torch.stack([(keys >> 32) & 0xFFFF, (keys >> 16) & 0xFFFF, keys & 0xFFFF], 1).to(torch.int32)
+
+
+class HR_Block(nn.Module):
+    def __init__(self, temp_wd_size: int = 50, max_range: int = 50, voxel_size: float = 0.2, conf_perc: float = 0.75,
+                 exclude_labels: Tuple[int] = None, resize: Tuple[int, int] = None):
+        super().__init__()
+        self.temp_wd_size = temp_wd_size
+        self.temp_bond = math.floor(temp_wd_size / 2)
+        self.max_range = max_range
+        self.voxel_size = voxel_size
+        self.min_offset = -math.ceil(max_range / voxel_size) - 1  # fixed origin (hr_module.py:53)
+        self.conf_perc = conf_perc
+        self.exclude_labels = torch.Tensor(exclude_labels) if exclude_labels else None
+        self.resize = resize
+
+    # ------------------------------------------------------------------ host-side window bookkeeping
+    def _plan(self, anchor_batch, ac_ref, hist_batch, hs_ref):
+        a_scene = [_scene_id(s) for s in anchor_batch["scene_name"]]
+        h_scene = [_scene_id(s) for s in hist_batch["scene_name"]]
+        a_id, h_id = list(anchor_batch["scan_ID"]), list(hist_batch["scan_ID"])
+        h_sizes = [int(hist_batch[hs_ref][j].shape[0]) for j in range(len(h_id))]
+        h_start = np.concatenate([[0], np.cumsum(h_sizes)]).astype(np.int64)
+        segs = []  # (anchor, frame, src_start, n)
+        for i in range(len(a_id)):
+            corr = [j for j in range(len(h_id))
+                    if h_scene[j] == a_scene[i] and abs(float(h_id[j]) - float(a_id[i])) <= self.temp_bond]
+            if not corr:
+                raise ValueError(f"HR_Block: anchor {i} has no frame of its scene in the hist batch")
+            if corr != list(range(corr[0], corr[-1] + 1)):
+                # the reference slices the hist logits sequentially from the first matching frame (quirk Q5) and is
+                # only meaningful for contiguous, ID-ordered windows, which is what its sequential loader produces
+                raise NotImplementedError("HR_Block: window frames must be contiguous in the batch (reference quirk Q5)")
+            for j in corr:
+                segs.append((i, j, int(h_start[j]), h_sizes[j]))
+        return segs, h_start, h_sizes
+
+    def forward(self, anchor_batch: Dict, anchor_type: str, hist_batch: Dict, hist_type: str) -> Dict:
+        required = ["seg_logit", "pose", "scene_name", "scan_ID", "ori_points"]
+        assert set(required) <= set(anchor_batch.keys())
+        assert set(required) <= set(hist_batch.keys())
+        assert anchor_type.upper() in ["2D", "3D"] and hist_type.upper() in ["2D", "3D"]
+        ac_ref = "img_indices" if anchor_type.upper() == "2D" else "ori_points"
+        hs_ref = "img_indices" if hist_type.upper() == "2D" else "ori_points"
+        a_logits, h_logits = anchor_batch["seg_logit"], hist_batch["seg_logit"]
+        dev = a_logits.device
+        B = len(anchor_batch["pose"])
+        C = a_logits.shape[1]
+        segs, h_start, h_sizes = self._plan(anchor_batch, ac_ref, hist_batch, hs_ref)
+        a_sizes = [int(anchor_batch[ac_ref][i].shape[0]) for i in range(B)]
+        for i in range(B):
+            assert anchor_batch["ori_points"][i].shape[0] == a_sizes[i]
+        for j in range(len(h_sizes)):
+            assert hist_batch["ori_points"][j].shape[0] == h_sizes[j]
+
+        # ---- device inputs
+        h_pts = torch.cat([p.reshape(-1, 3) for p in hist_batch["ori_points"]], 0).to(dev, torch.float32)
+        a_pts = torch.cat([p.reshape(-1, 3) for p in anchor_batch["ori_points"]], 0).to(dev, torch.float32)
+        Ph, Pa = h_pts.shape[0], a_pts.shape[0]
+        assert h_logits.shape[0] == Ph and a_logits.shape[0] == Pa
+        S = len(segs)
+        seg_n = np.array([s[3] for s in segs], dtype=np.int64)
+        seg_out = np.concatenate([[0], np.cumsum(seg_n)]).astype(np.int64)
+        E = int(seg_out[-1])
+        poses_a = [torch.as_tensor(p, dtype=torch.float64).cpu() for p in anchor_batch["pose"]]
+        poses_h = [torch.as_tensor(p, dtype=torch.float64).cpu() for p in hist_batch["pose"]]
+        inv_a = [torch.linalg.inv(p) for p in poses_a]
+        seg_T = torch.stack([(inv_a[i] @ poses_h[j])[:3].reshape(12) for (i, j, _, _) in segs], 0)
+        Wmax = max(sum(1 for s in segs if s[1] == j) for j in range(len(h_sizes)))
+        frame_seg = np.full((len(h_sizes), max(Wmax, 1)), -1, dtype=np.int32)
+        fill = [0] * len(h_sizes)
+        for si, (i, j, _, _) in enumerate(segs):  # segs are anchor-major => ascending anchor per frame
+            frame_seg[j, fill[j]] = si
+            fill[j] += 1
+        a_start = np.concatenate([[0], np.cumsum(a_sizes)]).astype(np.int64)
+        # one small H2D per table
+        d = lambda a, dt: torch.as_tensor(a, dtype=dt).to(dev)
+        seg_out_d = d(seg_out, torch.int64)
+        seg_src_d = d(np.array([s[2] for s in segs], dtype=np.int64), torch.int64)
+        seg_anchor_d = d(np.array([s[0] for s in segs], dtype=np.int32), torch.int32)
+        seg_T_d = seg_T.to(dev)
+        a_seg_out_d = d(a_start, torch.int64)
+        a_seg_anchor_d = torch.arange(B, dtype=torch.int32, device=dev)
+
+        # ---- keys, sort, segments
+        h_keys, h_src = ops.st_keys(h_pts, seg_out_d, seg_src_d, seg_anchor_d, seg_T_d, E, self.max_range,
+                                    self.voxel_size, self.min_offset)
+        a_keys, _ = ops.st_keys(a_pts, a_seg_out_d, a_seg_out_d[:-1].contiguous(), a_seg_anchor_d, None, Pa,
+                                self.max_range, self.voxel_size, self.min_offset)
+        h_selem, h_inv, h_uk, h_seg = ops.sort_segments(h_keys)
+        a_selem, a_inv, a_uk, a_seg = ops.sort_segments(a_keys)
+        Vt, Va = h_uk.numel(), a_uk.numel()
+
+        # ---- per-voxel means
+        h_probs, h_ety = ops.softmax_entropy(h_logits.detach().float().contiguous())
+        tr_voxel_probs = ops.segment_reduce(h_probs, h_selem, h_seg, "mean", src_index=h_src)
+        tr_voxel_ety = ops.segment_reduce(h_ety, h_selem, h_seg, "mean", src_index=h_src)
+        a_in = a_logits if a_logits.dtype == torch.float32 else a_logits.float()
+        ac_voxel_probs = _VoxelMeanSoftmax.apply(a_in.contiguous(), a_selem, a_inv, a_seg)
+
+        # ---- ST-voxel entropy written back to the hist points (mean over the anchors that see the point)
+        hs_pc_ety = ops.st_gather_back(tr_voxel_ety, h_inv, d(h_start, torch.int64), d(frame_seg, torch.int32),
+                                       seg_out_d, Ph)
+
+        # ---- correspondence
+        a_sel, t_sel = ops.st_join(a_uk, h_uk)
+        a_sel_l, t_sel_l = a_sel.long(), t_sel.long()
+        matched_keys = a_uk[a_sel_l]
+        per_anchor = torch.bincount((matched_keys >> 48), minlength=B).tolist()
+        if min(per_anchor) == 0:
+            print("No correspondence found!")
+            raise AssertionError
+        ac_first = a_selem[a_seg[:-1].long()].long()            # first in-range point of each anchor voxel
+        tr_first = h_src[h_selem[h_seg[:-1].long()].long()].long()  # ... of each hist voxel, as hist point index
+        vox = _decode_xyz(matched_keys)
+        split = lambda t: list(torch.split(t, per_anchor, 0))
+        tr_logits_all = tr_voxel_probs[t_sel_l]
+        out = {
+            "ac_logits": split(ac_voxel_probs[a_sel_l]),
+            "ac_voxels": split(vox),
+            "tr_logits": split(tr_logits_all),
+            "tr_voxels": split(vox.clone()),
+            "tr_ety_loss": [],
+            "tr_pc2img_mask": [],
+            "tr_img_points": [],
+            "ac_p2v_indices": split(ac_first[a_sel_l]),
+            "tr_p2v_indices": split(tr_first[t_sel_l]),
+            "hs_pc_ety": hs_pc_ety,
+        }
+        if self.conf_perc is not None and self.conf_perc > 0.0:
+            out["tr_conf_mask"] = refine_ety(tr_voxel_ety, tr_logits_all.argmax(1), self.conf_perc, num_classes=C)
+        else:
+            out["tr_conf_mask"] = torch.ones(t_sel.numel(), dtype=torch.bool, device=dev)
+        return out
+
+
+class CR_Block(nn.Module):
+    """Entropy-weighted KL between matched anchor / hist voxel distributions (hr_module.py:344-420)."""
+
+    def __init__(self, reduction="mean", conf_mask=False, ety_weight=False):
+        super().__init__()
+        self.reduction = reduction
+        self.conf_mask = conf_mask
+        self.ety_weight = ety_weight
+
+    def forward(self, logit_dict: Dict[str, torch.Tensor], self_corr: bool = False) -> torch.Tensor:
+        ac_list, tr_list = logit_dict["ac_logits"], logit_dict["tr_logits"]
+        sizes = [int(t.shape[0]) for t in ac_list]
+        ac = torch.cat(list(ac_list), 0)
+        tr = torch.cat(list(tr_list), 0).detach()
+        M = ac.shape[0]
+        dev = ac.device
+        # matched anchor/hist voxel lists are identical and sorted => the reference's two argsorts are the identity (Q3)
+        if self.ety_weight and not self_corr:
+            a_e = logit_dict["ac_pc_ety"][torch.cat(list(logit_dict["ac_p2v_indices"]), 0)]
+            t_e = logit_dict["tr_pc_ety"][torch.cat(list(logit_dict["tr_p2v_indices"]), 0)]
+            weight = torch.exp(-t_e) / (torch.exp(-t_e) + torch.exp(-a_e))
+        else:
+            weight = torch.ones(M, device=dev)
+        tr = torch.where(tr == 0.0, torch.full_like(tr, 1e-8), tr)  # Q6: applied to probabilities
+        ac = torch.where(ac == 0.0, torch.full_like(ac, 1e-8), ac)
+        row = weight * F.kl_div(torch.log(ac), tr, reduction="none").sum(1)
+        keep = logit_dict["tr_conf_mask"][:M].to(row.dtype) if self.conf_mask else torch.ones(M, device=dev)
+        anchor_of_row = torch.repeat_interleave(torch.arange(len(sizes), device=dev),
+                                                torch.as_tensor(sizes, device=dev))
+        num = torch.zeros(len(sizes), dtype=row.dtype, device=dev).index_add(0, anchor_of_row, row * keep)
+        den = torch.zeros(len(sizes), dtype=row.dtype, device=dev).index_add(0, anchor_of_row, keep)
+        return (num / den).sum() / len(sizes)

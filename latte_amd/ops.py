@@ -280,3 +280,116 @@ def devoxelize_bwd(gout, idx, w, V: int):
     gf = torch.empty((V, C), dtype=torch.float32, device=gout.device)
     _lib.call("lt_devoxelize_bwd", _p(gout), _p(idx), _p(w), _p(gf), N, C, V, _stream())
     return gf
+
+
+# ------------------------------------------------------------------ ST-voxel aggregation (include/latte_hip_st.h)
+def softmax_entropy(logits: torch.Tensor, want_probs=True, want_ety=True):
+    logits = _chk(logits, torch.float32, "softmax_entropy logits")
+    P, C = logits.shape
+    probs = torch.empty_like(logits) if want_probs else None
+    ety = torch.empty(P, dtype=torch.float32, device=logits.device) if want_ety else None
+    _lib.call("lt_softmax_entropy", _p(logits), P, C, _p(probs), _p(ety), _stream())
+    return probs, ety
+
+
+def softmax_bwd(probs, gprobs):
+    probs = _chk(probs, torch.float32, "softmax_bwd probs")
+    gprobs = _chk(gprobs, torch.float32, "softmax_bwd g")
+    out = torch.empty_like(probs)
+    _lib.call("lt_softmax_bwd", _p(probs), _p(gprobs), probs.shape[0], probs.shape[1], _p(out), _stream())
+    return out
+
+
+def st_keys(points, seg_out_start, seg_src_start, seg_anchor, seg_T, E: int, max_range, voxel_size, min_offset):
+    points = _chk(points, torch.float32, "st_keys points")
+    S = seg_anchor.numel()
+    keys = torch.empty(E, dtype=torch.int64, device=points.device)
+    src = torch.empty(E, dtype=torch.int32, device=points.device)
+    _lib.call("lt_st_keys", _p(points), _p(_chk(seg_out_start, torch.int64, "seg_out_start")),
+              _p(_chk(seg_src_start, torch.int64, "seg_src_start")), _p(_chk(seg_anchor, torch.int32, "seg_anchor")),
+              _p(None if seg_T is None else _chk(seg_T, torch.float64, "seg_T")), S, int(E), float(max_range),
+              float(voxel_size), int(min_offset), _p(keys), _p(src), _stream())
+    return keys, src
+
+
+def sort_segments(keys: torch.Tensor):
+    """-> (sorted_elem int32 [E], inverse int32 [E], uniq_keys int64 [V], seg_start int32 [V+1])."""
+    keys = _chk(keys.reshape(-1), torch.int64, "sort_segments keys")
+    E = keys.numel()
+    dev = keys.device
+    lib = _lib.load()
+    ws = _ws(lib.lt_sort_segments_workspace_bytes(E), dev)
+    selem = torch.empty(E, dtype=torch.int32, device=dev)
+    inv = torch.empty(E, dtype=torch.int32, device=dev)
+    uk = torch.empty(max(E, 1), dtype=torch.int64, device=dev)
+    seg = torch.zeros(E + 1, dtype=torch.int32, device=dev)
+    v = ctypes.c_int64(0)
+    _lib.call("lt_sort_segments", _p(keys), E, 63, _p(ws), ws.numel(), _p(selem), _p(inv), _p(uk), _p(seg),
+              ctypes.byref(v), _stream())
+    V = v.value
+    return selem, inv, uk[:V], seg[:V + 1]
+
+
+_MODES = {"sum": 0, "add": 0, "mean": 1, "max": 2}
+
+
+def segment_reduce(src, sorted_elem, seg_start, mode: str, src_index=None, want_argmax=False):
+    src = _chk(src, torch.float32, "segment_reduce src")
+    squeeze = src.dim() == 1
+    s2 = src.reshape(src.shape[0], -1)
+    C = s2.shape[1]
+    V = seg_start.numel() - 1
+    out = torch.empty((V, C), dtype=torch.float32, device=src.device)
+    arg = torch.empty((V, C), dtype=torch.int32, device=src.device) if want_argmax else None
+    _lib.call("lt_segment_reduce", _p(s2), C, _p(src_index), _p(sorted_elem), _p(seg_start), V, _MODES[mode], _p(out),
+              _p(arg), _stream())
+    out = out.reshape(V) if squeeze else out.reshape((V,) + tuple(src.shape[1:]))
+    return (out, arg) if want_argmax else out
+
+
+def segment_reduce_bwd(gout, inverse, seg_start, mean: bool):
+    gout = _chk(gout, torch.float32, "segment_reduce_bwd g")
+    g2 = gout.reshape(gout.shape[0], -1)
+    C = g2.shape[1]
+    E = inverse.numel()
+    ge = torch.empty((E, C), dtype=torch.float32, device=gout.device)
+    _lib.call("lt_segment_reduce_bwd", _p(g2), C, _p(inverse), _p(seg_start), E, int(mean), _p(ge), _stream())
+    return ge.reshape((E,) + tuple(gout.shape[1:]))
+
+
+def st_gather_back(voxel_ety, inverse, frame_start, frame_seg, seg_out_start, P: int):
+    F, Wmax = frame_seg.shape
+    out = torch.empty(P, dtype=torch.float32, device=inverse.device)
+    _lib.call("lt_st_gather_back", _p(_chk(voxel_ety, torch.float32, "voxel_ety")), _p(inverse),
+              _p(_chk(frame_start, torch.int64, "frame_start")), F, _p(_chk(frame_seg, torch.int32, "frame_seg")), Wmax,
+              _p(seg_out_start), int(P), _p(out), _stream())
+    return out
+
+
+def st_join(a_keys, t_keys):
+    """sorted int64 key arrays -> (a_sel int32 [M], t_sel int32 [M]) matched voxel ids, ascending."""
+    a_keys = _chk(a_keys, torch.int64, "st_join a_keys")
+    t_keys = _chk(t_keys, torch.int64, "st_join t_keys")
+    Va, Vt = a_keys.numel(), t_keys.numel()
+    lib = _lib.load()
+    ws = _ws(lib.lt_st_join_workspace_bytes(Va, Vt), a_keys.device)
+    cap = max(min(Va, Vt), 1)
+    a_sel = torch.empty(max(Va, 1), dtype=torch.int32, device=a_keys.device)
+    t_sel = torch.empty(max(Vt, 1), dtype=torch.int32, device=a_keys.device)
+    m = ctypes.c_int64(0)
+    _lib.call("lt_st_join", _p(a_keys), Va, _p(t_keys), Vt, _p(ws), ws.numel(), _p(a_sel), _p(t_sel), ctypes.byref(m),
+              _stream())
+    del cap
+    return a_sel[:m.value], t_sel[:m.value]
+
+
+def class_quantile_mask(ety, label, num_classes: int, q: float):
+    ety = _chk(ety, torch.float32, "class_quantile ety")
+    label = _chk(label, torch.int32, "class_quantile label")
+    n = ety.numel()
+    lib = _lib.load()
+    ws = _ws(lib.lt_class_quantile_workspace_bytes(n), ety.device)
+    mask = torch.empty(n, dtype=torch.uint8, device=ety.device)
+    _lib.call("lt_class_quantile_mask", _p(ety), _p(label), n, int(num_classes), float(q), _p(ws), ws.numel(), _p(mask),
+              _stream())
+    return mask.bool()

@@ -1,0 +1,106 @@
+"""GPU parity of the ST-voxel aggregation (HR_Block / CR_Block / refine_ety / scatter) against the golden vectors
+captured from the reference's own hr_module.py (tests/golden/hr_*.npz) and against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import hr_ref
+from tests.helpers import HR_CASES, hr_roles, load_hr_case
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-3
+
+
+def to_dev(b):
+    out = dict(b)
+    out["seg_logit"] = b["seg_logit"].cuda() if not b["seg_logit"].requires_grad else b["seg_logit"]
+    return out
+
+
+@pytest.mark.parametrize("case", HR_CASES)
+@pytest.mark.parametrize("tag", ["23", "32"])
+def test_hr_cr_block_matches_reference_golden(case, tag):
+    from latte_amd.hr_module import CR_Block, HR_Block
+    z, cfg, batch = load_hr_case(case)
+    ab, at, hb, ht, a_lg = hr_roles(z, batch, tag)
+    a_dev = a_lg.cuda().requires_grad_(True)
+    ab = dict(ab, seg_logit=a_dev)
+    hb = dict(hb, seg_logit=hb["seg_logit"].cuda())
+    hr = HR_Block(cfg["temp_wd_size"], cfg["max_range"], cfg["voxel_size"], cfg["conf_perc"])
+    d = hr(ab, at, hb, ht)
+    assert set(d.keys()) == {"ac_logits", "ac_voxels", "tr_logits", "tr_voxels", "tr_conf_mask", "tr_ety_loss",
+                             "tr_pc2img_mask", "tr_img_points", "ac_p2v_indices", "tr_p2v_indices", "hs_pc_ety"}
+    for i in range(cfg["B"]):
+        for k in ("ac_voxels", "tr_voxels", "ac_p2v_indices", "tr_p2v_indices"):  # bit-exact index structures
+            assert np.array_equal(d[k][i].cpu().numpy(), z[f"{tag}_{k}_{i}"]), (k, i)
+        for k in ("ac_logits", "tr_logits"):
+            assert np.allclose(d[k][i].detach().cpu().numpy(), z[f"{tag}_{k}_{i}"], rtol=RTOL, atol=1e-6), (k, i)
+    assert np.allclose(d["hs_pc_ety"].cpu().numpy(), z[f"{tag}_hs_pc_ety"], rtol=RTOL, atol=1e-6)
+    got_mask, want_mask = d["tr_conf_mask"].cpu().numpy(), z[f"{tag}_tr_conf_mask"]
+    assert got_mask.shape == want_mask.shape
+    # an entropy equal to its class threshold within 1 ulp may fall on either side
+    assert (got_mask != want_mask).sum() <= 2
+    d["ac_pc_ety"] = torch.from_numpy(z[f"{tag}_ac_pc_ety"]).cuda()
+    d["tr_pc_ety"] = torch.from_numpy(z[f"{tag}_tr_pc_ety"]).cuda()
+    if (got_mask != want_mask).any():
+        d["tr_conf_mask"] = torch.from_numpy(want_mask).cuda()
+    loss = CR_Block(reduction="mean", conf_mask=True, ety_weight=True)(d)
+    want = float(z[f"{tag}_cr_loss"])
+    assert abs(float(loss.detach()) - want) < RTOL * abs(want)
+    loss.backward()
+    g, gw = a_dev.grad.cpu().numpy(), z[f"{tag}_grad_anchor_logit"]
+    assert np.linalg.norm(g - gw) < RTOL * np.linalg.norm(gw)
+
+
+def test_softmax_entropy_and_refine_known_answers():
+    from latte_amd import ops
+    from latte_amd.hr_module import refine_ety
+    z, cfg, _ = load_hr_case("tiny")
+    g = torch.Generator().manual_seed(0)
+    logits = 3 * torch.randn(5000, 9, generator=g)
+    probs, ety = ops.softmax_entropy(logits.cuda())
+    want_p = torch.softmax(logits, 1)
+    assert torch.allclose(probs.cpu(), want_p, rtol=1e-5, atol=1e-7)
+    assert torch.allclose(ety.cpu(), hr_ref.prob_2_entropy(want_p).sum(1), rtol=1e-4, atol=1e-6)
+    m = refine_ety(torch.from_numpy(z["refine_ety_in_ety"]).cuda(), torch.from_numpy(z["refine_ety_in_label"]).cuda(), 0.75)
+    assert np.array_equal(m.cpu().numpy(), z["refine_ety_mask"])
+
+
+@pytest.mark.parametrize("reduce", ["mean", "sum", "max"])
+def test_scatter_shim_matches_oracle(reduce):
+    import latte_amd
+    latte_amd.install_shims()
+    import torch_scatter.scatter as ts_scatter  # exactly how the reference imports it (hr_module.py:5)
+    g = torch.Generator().manual_seed(1)
+    idx = torch.randint(0, 700, (20000,), generator=g)
+    idx[idx == 13] = 14  # a hole: row 13 stays zero
+    src = torch.randn(20000, 9, generator=g, requires_grad=True)
+    n = int(idx.max()) + 1
+    if reduce == "max":
+        want = torch.full((n, 9), -float("inf")).scatter_reduce(0, idx[:, None].expand(-1, 9), src, "amax")
+        want = torch.where(torch.isinf(want), torch.zeros_like(want), want)
+    else:
+        want = torch.zeros(n, 9).index_add(0, idx, src)
+        if reduce == "mean":
+            want = want / torch.bincount(idx, minlength=n).clamp(min=1)[:, None]
+    gw = torch.randn(n, 9, generator=g)
+    want.backward(gw)
+    s2 = src.detach().cuda().requires_grad_(True)
+    got = ts_scatter(s2, idx.cuda(), dim=0, reduce=reduce)
+    assert torch.allclose(got.detach().cpu(), want.detach(), rtol=1e-5, atol=1e-6)
+    got.backward(gw.cuda())
+    assert torch.allclose(s2.grad.cpu(), src.grad, rtol=1e-5, atol=1e-6)
+    # 1-D source (the entropy call site hr_module.py:252)
+    e = torch.rand(20000, generator=g)
+    got1 = ts_scatter(e.cuda(), idx.cuda(), dim=0, reduce="mean")
+    assert torch.allclose(got1.cpu(), hr_ref.scatter_mean(e, idx), rtol=1e-5, atol=1e-7)
+
+
+def test_hr_block_raises_like_reference_when_nothing_corresponds():
+    from latte_amd.hr_module import HR_Block
+    z, cfg, batch = load_hr_case("tiny")
+    ab, at, hb, ht, a_lg = hr_roles(z, batch, "32")
+    ab = dict(ab, seg_logit=a_lg.cuda(), ori_points=[p + 25.0 for p in ab["ori_points"]])  # anchors moved away
+    hb = dict(hb, seg_logit=hb["seg_logit"].cuda())
+    with pytest.raises(AssertionError):
+        HR_Block(cfg["temp_wd_size"], cfg["max_range"], cfg["voxel_size"], cfg["conf_perc"])(ab, at, hb, ht)
