@@ -80,6 +80,9 @@ def load() -> ctypes.CDLL:
         raise LatteHipError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(make -C latte_amd/csrc). There is no CPU fallback for the product path.")
+    # torch ships its own libamdhip64.so.7; it must be the HIP runtime of the process BEFORE this library is mapped,
+    # so that both resolve the same SONAME to ONE runtime (streams and device pointers are shared with torch).
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so is stale

@@ -1,0 +1,184 @@
+"""One Latte TTA iteration, 3-D side (the unit BASELINE.json's metric counts).
+
+Host-side restatement of latte/tta/tools/latte.py:133-323 with the 2-D SegFormer replaced by given 2-D logits
+(the 2-D branch is out of scope; the synthetic bench feeds random camera-FOV logits):
+  teacher 3-D forward (no grad) -> inverse_to_all -> camera-FOV subset                    latte.py:156-167
+  student 3-D forward -> inverse_to_all                                                   :176-178
+  HR_Block(student 2D | teacher 3D), HR_Block(student 3D | teacher 2D)                    :199-202
+  entropy-weighted pseudo-label fusion + refine_pseudo_labels                             :207-238
+  CR_Block x2, cross-entropy on the pseudo labels                                         :276-303
+  backward to the norm parameters, (multi-GPU: one flat RCCL all-reduce), Adam, EMA       :313-323
+Model configuration helpers mirror latte/common/utils/ema_util.py:6-41,74-118."""
+from __future__ import annotations
+
+from copy import deepcopy
+from typing import Dict, List
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .hr_module import CR_Block, HR_Block, prob_2_entropy
+from .spvcnn import inverse_to_all
+
+__all__ = ["configure_model_norm", "create_ema_model", "update_ema_norm", "refine_pseudo_labels", "pc2img_logit",
+           "LatteStep"]
+
+
+def configure_model_norm(model: nn.Module, reset_dropout: bool = True):
+    """ema_util.configure_model_norm: train mode, only *norm* modules trainable, BN on batch statistics."""
+    model.train()
+    model.requires_grad_(False)
+    for _, m in model.named_modules():
+        name = type(m).__name__.lower()
+        if "norm" in name:
+            m.requires_grad_(True)
+            if "batchnorm" in name:
+                m.track_running_stats = False
+                m.running_mean = None
+                m.running_var = None
+        elif reset_dropout and "dropout" in name:
+            m.p = 0.0
+    return model
+
+
+def create_ema_model(model: nn.Module) -> nn.Module:
+    ema = deepcopy(model)
+    for p in ema.parameters():
+        p.detach_()
+    for _, m in ema.named_modules():
+        if "dropout" in type(m).__name__.lower():
+            m.p = 0.0
+    return ema
+
+
+def _norm_params(model: nn.Module) -> List[torch.Tensor]:
+    out = []
+    for m in model.modules():
+        if "norm" in type(m).__name__.lower():
+            out.extend(m.parameters(recurse=False))
+    return out
+
+
+@torch.no_grad()
+def update_ema_norm(ema_model: nn.Module, model: nn.Module, alpha: float = 0.99) -> nn.Module:
+    """ema = alpha*ema + (1-alpha)*student on the norm parameters (ema_util.update_ema_norm), as two multi-tensor ops."""
+    e, s = _norm_params(ema_model), _norm_params(model)
+    torch._foreach_mul_(e, alpha)
+    torch._foreach_add_(e, s, alpha=1.0 - alpha)
+    return ema_model
+
+
+def refine_pseudo_labels(probs: torch.Tensor, pseudo_label: torch.Tensor, ignore_label: int = -100) -> torch.Tensor:
+    """latte/data/utils/refine_pseudo_labels.py:10-30: per class, labels below min(class median, 0.9) are ignored."""
+    for cls in pseudo_label.unique():
+        idx = torch.nonzero(pseudo_label == cls).squeeze(1)
+        thresh = probs[idx].median().clamp(max=0.9)
+        pseudo_label[idx[probs[idx] < thresh]] = ignore_label
+    return pseudo_label
+
+
+def pc2img_logit(pc_logits: torch.Tensor, pc2img_idx_ls: List[torch.Tensor]):
+    """latte/data/utils/all_to_partial.py:4-37 with return_mask=True: per-scan bool maps -> (mask over all points,
+    logits of the in-FOV points)."""
+    mask = torch.cat(list(pc2img_idx_ls), 0)
+    return mask, pc_logits[mask]
+
+
+class LatteStep:
+    def __init__(self, model_3d: nn.Module, num_classes: int, hr_cfg: Dict, lr: float = 1e-3, conf_perc=None,
+                 lambda_hr_23: float = 0.3, lambda_hr_32: float = 0.3, lambda_ety_ps: float = 1.0, class_weights=None,
+                 process_group=None):
+        self.model = configure_model_norm(model_3d, reset_dropout=True)
+        self.ema_model = create_ema_model(self.model)
+        self.hr = HR_Block(**hr_cfg)
+        self.cr = CR_Block(reduction="mean", conf_mask=True, ety_weight=True)
+        self.params = [p for p in self.model.parameters() if p.requires_grad]
+        self.optimizer = torch.optim.Adam(self.params, lr=lr)
+        self.conf_perc = hr_cfg.get("conf_perc") if conf_perc is None else conf_perc
+        self.lam23, self.lam32, self.lam_ps = lambda_hr_23, lambda_hr_32, lambda_ety_ps
+        self.class_weights = class_weights
+        self.num_classes = num_classes
+        self.pg = process_group
+        self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
+
+    # -------------------------------------------------------------------------------------------------
+    def forward_backward(self, batch: Dict):
+        """-> dict of losses.  batch: see latte_amd.workload.build_batch."""
+        extra = {k: batch[k] for k in ("pose", "scene_name", "scan_ID", "img_indices")}
+        pc2img = batch["pc2img_idx"]
+        with torch.no_grad():
+            ema3d = self.ema_model(batch)
+            ema3d["seg_logit"] = inverse_to_all(ema3d["seg_logit"], batch)
+            pc2img_mask, ema_logit_3d = pc2img_logit(ema3d["seg_logit"], pc2img)
+        ema_logit_2d = batch["logit_2d_teacher"]
+        preds_2d = {"seg_logit": batch["logit_2d_student"]}
+        preds_3d = self.model(batch)
+        preds_3d["seg_logit"] = inverse_to_all(preds_3d["seg_logit"], batch)
+
+        ori_2d = [p[m] for p, m in zip(batch["ori_points"], pc2img)]
+        a2 = dict(preds_2d, ori_points=ori_2d, **extra)
+        h2 = dict(seg_logit=ema_logit_2d, ori_points=ori_2d, **extra)
+        a3 = dict(seg_logit=preds_3d["seg_logit"], ori_points=batch["ori_points"], **extra)
+        h3 = dict(seg_logit=ema3d["seg_logit"], ori_points=batch["ori_points"], **extra)
+        hr23 = self.hr(a2, "2D", h3, "3D")
+        hr32 = self.hr(a3, "3D", h2, "2D")
+
+        # ---- pseudo labels (latte.py:207-238)
+        with torch.no_grad():
+            probs_2d = F.softmax(ema_logit_2d, 1)
+            all_probs_3d = F.softmax(ema3d["seg_logit"], 1)
+            probs_3d = F.softmax(ema_logit_3d, 1)
+            st3, st2 = hr23["hs_pc_ety"], hr32["hs_pc_ety"]
+            v3, v2 = st3 != 0, st2 != 0
+            if self.conf_perc is not None and self.conf_perc >= 0:
+                v3 = torch.logical_and(st3 <= torch.quantile(st3, self.conf_perc), v3)
+                v2 = torch.logical_and(st2 <= torch.quantile(st2, self.conf_perc), v2)
+            pc2 = prob_2_entropy(probs_2d).sum(1)
+            pc3 = prob_2_entropy(all_probs_3d).sum(1)
+            pc2 = torch.where(v2, st2, pc2)
+            pc3 = torch.where(v3, st3, pc3)
+            rv2, rv3 = torch.exp(-pc2), torch.exp(-pc3)
+            rv3m = rv3[pc2img_mask]
+            w2 = rv2 / (rv2 + rv3m)
+            w3 = rv3m / (rv2 + rv3m)
+            ps_prob = all_probs_3d
+            ps_prob[pc2img_mask] = w2.unsqueeze(1) * probs_2d + w3.unsqueeze(1) * probs_3d
+            ps_conf, ps_label = ps_prob.max(1)
+            ps_label = refine_pseudo_labels(ps_conf, ps_label)
+
+        loss_2d, loss_3d = [], []
+        hr23.update({"ac_pc_ety": pc2, "tr_pc_ety": pc3})
+        l23 = self.cr(hr23)
+        loss_2d.append(self.lam23 * l23)
+        hr32.update({"ac_pc_ety": pc3, "tr_pc_ety": pc2})
+        l32 = self.cr(hr32)
+        loss_3d.append(self.lam32 * l32)
+        pl2 = F.cross_entropy(preds_2d["seg_logit"], ps_label[pc2img_mask].long(), weight=self.class_weights)
+        pl3 = F.cross_entropy(preds_3d["seg_logit"], ps_label.long(), weight=self.class_weights)
+        loss_2d.append(pl2)
+        loss_3d.append(pl3)
+        (sum(loss_3d) + sum(loss_2d)).backward()
+        return {"hr_23": l23.detach(), "hr_32": l32.detach(), "pl_2d": pl2.detach(), "pl_3d": pl3.detach()}
+
+    def allreduce_grads(self):
+        """The only collective of the path: ONE flat RCCL all-reduce of the norm gradients (13 248 floats at cr=1)."""
+        if self.world == 1:
+            return
+        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        torch.distributed.all_reduce(flat, group=self.pg)
+        flat.div_(self.world)
+        off = 0
+        for p, g in zip(self.params, grads):
+            n = g.numel()
+            p.grad = flat[off:off + n].view_as(p)
+            off += n
+
+    def step(self, batch: Dict):
+        self.optimizer.zero_grad(set_to_none=True)
+        losses = self.forward_backward(batch)
+        self.allreduce_grads()
+        self.optimizer.step()
+        update_ema_norm(self.ema_model, self.model, 0.99)
+        return losses

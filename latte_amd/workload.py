@@ -1,0 +1,51 @@
+"""Synthetic TTA batches for the BASELINE.json configs: raw scans from latte_amd.synth are pushed through
+the dataloader's voxelization contract ON THE GPU (quantize_scan_gpu: round(p*20)-min, unique 5 cm voxels, first-point
+features), collated like latte/data/collate.py:403-421, and completed with the per-scan metadata HR_Block needs."""
+from __future__ import annotations
+
+from typing import Dict
+
+import numpy as np
+import torch
+
+from . import synth
+from .quantize import quantize_scan_gpu
+from .tensor import SparseTensor
+
+__all__ = ["build_batch", "hr_cfg_of"]
+
+
+def hr_cfg_of(w: Dict) -> Dict:
+    return dict(temp_wd_size=w["W"], max_range=w["R"], voxel_size=w["vs"], conf_perc=0.9)
+
+
+def build_batch(w: Dict, device="cuda", scan_offset: int = 0, seed: int = 0) -> Dict:
+    """w: a latte_amd.synth.WORKLOADS entry.  scan_offset shifts the scan/sequence ids (multi-GPU sharding: every rank
+    builds its own sequences)."""
+    B, n, C, seq_len = w["B"], w["n"], w["C"], w["seq_len"]
+    coords, feats, indices, inverse, ori, fov, poses, scenes, ids = [], [], [], [], [], [], [], [], []
+    for b in range(B):
+        gid = scan_offset + b
+        pts_np, inten_np = synth.make_scan(n, gid, beams=w["beams"], full_360=w["full_360"])
+        pts = torch.from_numpy(pts_np).to(device)
+        inten = torch.from_numpy(inten_np).to(device)
+        c, f, inds, inv = quantize_scan_gpu(pts, inten, scale=20)
+        coords.append(torch.cat([c, torch.full((c.shape[0], 1), b, dtype=torch.int32, device=device)], 1))
+        feats.append(f)
+        indices.append(inds)
+        inverse.append(inv)
+        ori.append(pts)
+        fov.append((pts[:, 0] > 0) & (pts[:, 1].abs() < 0.8 * pts[:, 0]))  # camera frustum stand-in (bool map)
+        poses.append(torch.from_numpy(synth.make_pose(gid % seq_len)))
+        scenes.append(f"scene-{1000 + gid // seq_len:04d}")
+        ids.append(gid % seq_len)
+    lidar = SparseTensor(torch.cat(feats, 0), torch.cat(coords, 0), 1)
+    n_fov = int(sum(int(m.sum()) for m in fov))
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    l2s = (3 * torch.randn(n_fov, C, generator=g)).to(device).requires_grad_(True)
+    l2t = (3 * torch.randn(n_fov, C, generator=g)).to(device)
+    return {
+        "lidar": lidar, "indices": indices, "inverse_map": inverse, "ori_points": ori, "pc2img_idx": fov,
+        "img_indices": [torch.empty(int(m.sum()), 2) for m in fov], "pose": poses, "scene_name": scenes, "scan_ID": ids,
+        "logit_2d_student": l2s, "logit_2d_teacher": l2t, "n_points": B * n, "n_voxels": int(lidar.C.shape[0]),
+    }
