@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Headline benchmark: points/s of one Latte TTA step (3-D side) on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A step = teacher SPVCNN forward + student SPVCNN forward + 2x HR_Block (ST-voxel aggregation) + pseudo-label fusion +
+2x CR_Block + cross-entropy + backward to the BatchNorm parameters + (N>1: one flat RCCL all-reduce of those grads) +
+Adam + EMA teacher update -- latte/tta/tools/latte.py:156-323 without the 2-D SegFormer.
+Workload at every N: BASELINE.json configs[1] (nuScenes-like 34 816-point 360-degree scans, 5-frame ST window, 6 scans
+per step and GPU, 16 classes, SPVCNN cr=1.0, fp32); every rank owns its own sequence (weak scaling, no data-path
+collective).  Inputs are resident in HBM before the timed region.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline      the dominant kernel family (sparse-conv fp32 MFMA kernel): algorithmic flops / HIP-event time of its
+                launches inside the timed region
+  cpu_baseline  the CPU oracle (oracle/step_ref.py, a port: the reference's torchsparse backend is not installable)
+                timed on this box's host cores on a bounded sample of the same workload
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense, spec
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="nuscenes_34k_w5")
+    ap.add_argument("--cr", type=float, default=1.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-scans", type=int, default=3, help="scans in the CPU-oracle sample")
+    ap.add_argument("--no-kernel-events", action="store_true", help="do not time the conv launches with HIP events")
+    ap.add_argument("--fwd-only", action="store_true", help="time teacher forward only (BASELINE config 5 style)")
+    return ap.parse_args()
+
+
+def cpu_baseline(w, cr, n_scans, seed=1):
+    """Oracle TTA step (teacher fwd, student fwd, 2x HR, 2x CR, CE, backward) on `n_scans` scans of the workload."""
+    import numpy as np
+    import torch
+    from latte_amd import synth
+    from latte_amd.spvcnn import Net3DSeg
+    from latte_amd.workload import hr_cfg_of
+    from oracle import step_ref
+
+    torch.manual_seed(seed)
+    model = Net3DSeg(w["C"], True, "SPVCNN", {"cr": cr})
+    sd = model.state_dict()
+    names = [f"{mn}.{pn}"[len("net_3d."):] for mn, mod in model.named_modules()
+             if isinstance(mod, torch.nn.BatchNorm1d) and mn.startswith("net_3d.") for pn, _ in mod.named_parameters()]
+    scans = [synth.make_scan(w["n"], j, beams=w["beams"], full_360=w["full_360"]) for j in range(n_scans)]
+    ori = [torch.from_numpy(p) for p, _ in scans]
+    fov = [(p[:, 0] > 0) & (p[:, 1].abs() < 0.8 * p[:, 0]) for p in ori]
+    n_fov = int(sum(int(m.sum()) for m in fov))
+    g = torch.Generator().manual_seed(0)
+    l2s = 3 * torch.randn(n_fov, w["C"], generator=g)
+    l2t = 3 * torch.randn(n_fov, w["C"], generator=g)
+    cores = torch.get_num_threads()
+    t0 = time.perf_counter()
+    coords, feats, invs, sizes = step_ref.quantize_batch(scans)
+    step_ref.tta_step_ref(sd, sd, coords, torch.from_numpy(feats), invs, sizes, ori, fov,
+                          [synth.make_pose(j) for j in range(n_scans)], ["scene-1000"] * n_scans, list(range(n_scans)),
+                          l2s, l2t, hr_cfg_of(w), grad_names=names)
+    dt = time.perf_counter() - t0
+    pts = n_scans * w["n"]
+    return {"value": pts / dt, "unit": "points/s", "cores": int(cores), "kind": "port",
+            "sample": f"one oracle TTA step (oracle/step_ref.py: quantize, teacher fwd, student fwd, 2x HR, 2x CR, CE, "
+                      f"backward) on {n_scans} scans x {w['n']} points of the same workload, {dt:.1f} s, torch-CPU "
+                      f"fp32 with {cores} threads; the reference's own backend (torchsparse v1.4.0 CUDA) cannot run here"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from latte_amd import _lib, ops, synth
+    from latte_amd.spvcnn import Net3DSeg
+    from latte_amd.tta_step import LatteStep
+    from latte_amd.workload import build_batch, hr_cfg_of
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    _lib.load()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    pg = None
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+        pg = dist.group.WORLD
+
+    w = synth.workload(args.workload)
+    torch.manual_seed(1)  # cfg.RNG_SEED (latte/common/config/base.py:173); same weights on every rank
+    model = Net3DSeg(w["C"], True, "SPVCNN", {"cr": args.cr}).to(dev)
+    step = LatteStep(model, w["C"], hr_cfg_of(w), process_group=pg)
+    batch = build_batch(w, device=dev, scan_offset=rank * w["B"], seed=rank)
+    n_points = batch["n_points"]
+
+    def one_step():
+        if args.fwd_only:
+            with torch.no_grad():
+                return step.ema_model(batch)
+        return step.step(batch)
+
+    for _ in range(args.warmup):
+        one_step()
+    trace = None if args.no_kernel_events else []
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ops.CONV_TRACE = trace
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    ops.CONV_TRACE = None
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    pairs = None
+    if trace:
+        # pair counts M of every conv launch of a step, from one more (untimed) step on every rank: the launch sequence
+        # and the kernel maps are the same in every step (same scans), only the BN parameters move
+        ops.CONV_PAIRS = []
+        one_step()
+        torch.cuda.synchronize()
+        pairs = [int(m.item()) for m in ops.CONV_PAIRS]
+        ops.CONV_PAIRS = None
+
+    if rank == 0:
+        roof = None
+        if trace:
+            per_step = len(trace) // args.steps
+            assert len(pairs) == per_step, (len(pairs), per_step)
+            flops_step, ms_total = 0.0, 0.0
+            for m, (_e0, _e1, cin, cout, _k, _v) in zip(pairs, trace[:per_step]):
+                flops_step += 2.0 * m * cin * cout
+            for (e0, e1, *_r) in trace:
+                ms_total += e0.elapsed_time(e1)
+            launches = len(trace)
+            flops_total = flops_step * args.steps
+            achieved = flops_total / (ms_total * 1e-3) / 1e12
+            roof = {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "kernel": "k_spconv_vec/k_spconv_scalar (fp32 MFMA sparse conv, all launches of the timed region)",
+                    "launches": launches, "avg_launch_us": round(1e3 * ms_total / launches, 2),
+                    "flops_per_launch": round(flops_total / launches),
+                    "share_of_step": round(ms_total * 1e-3 / dt, 4)}
+            pmc = os.path.join(ROOT, "profiles", "conv_traffic.json")
+            if os.path.exists(pmc):
+                try:
+                    roof["traffic"] = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                except Exception:
+                    pass
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(w, args.cr, args.cpu_scans)
+        out = {
+            "metric": "points/sec per sparse-conv 3D fwd+ST-voxel TTA step" if not args.fwd_only else "points/sec, 3D fwd only",
+            "value": n_points * world * args.steps / dt, "unit": "points/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "scans_per_gpu": w["B"], "points_per_scan": w["n"], "classes": w["C"],
+                       "st_window": w["W"], "st_voxel_m": w["vs"], "max_range_m": w["R"], "spvcnn_cr": args.cr,
+                       "voxels_per_gpu": batch["n_voxels"], "parallelism": f"dp{world} (sequences sharded)"},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -82,6 +82,13 @@ int lt_kmap_pairs(const int32_t* results, int32_t K, int64_t Vout, void* ws, int
 /* reverse table for transposed conv / backward: rev[k*Vin+i] = o where results[k*Vout+o] == i, else -1 */
 int lt_kmap_reverse(const int32_t* results, int32_t K, int64_t Vout, int64_t Vin, int32_t* rev, lt_stream_t stream);
 
+/* Processing order for lt_spconv_fwd over a neighbour table [K,V] (results or rev): the rows sorted (stable) by their
+ * K-bit "which offsets have a neighbour" mask, so that the 16-row MFMA strips of the conv kernel hold rows with the
+ * same offsets.  No counterpart in torchsparse (it gathers per offset); results do not depend on the order. No sync. */
+int64_t lt_kmap_order_workspace_bytes(int64_t V);
+int lt_kmap_order(const int32_t* table, int32_t K, int64_t V, void* ws, int64_t ws_bytes, int32_t* order,
+                  lt_stream_t stream);
+
 /* ------------------------------------------------------------------ sparse convolution
  * spnn.Conv3d forward / backward-input (basic_blocks.py:17,34,51,58,68; spvcnn.py:30,32):
  *   out[o,:] = sum_k in[nbr[k,o],:] @ Wk      (rows with nbr<0 contribute nothing)

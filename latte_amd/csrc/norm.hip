@@ -91,33 +91,48 @@ __global__ __launch_bounds__(BN_BLOCK) void k_col_partial(Op op, int64_t V, int 
   }
 }
 
-__global__ void k_bn_finalize(const float* __restrict__ partial, int nb, const float* __restrict__ x, int64_t V, int C,
-                              float* __restrict__ mean, float* __restrict__ var) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int b = 0; b < nb; ++b) {
-    s1 += (double)partial[(int64_t)b * 2 * C + c];
-    s2 += (double)partial[(int64_t)b * 2 * C + C + c];
-  }
-  const double m = s1 / (double)V;
-  double v = s2 / (double)V - m * m;
-  if (v < 0.0) v = 0.0;
-  mean[c] = (float)((double)x[c] + m);
-  var[c] = (float)v;
+// one wave per channel: lane l sums partials l, l+64, ... in fp64, then a wave reduction (fixed order => deterministic)
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
 }
 
-__global__ void k_sum_partials(const float* __restrict__ partial, int nb, int C, float* __restrict__ out_a,
-                               float* __restrict__ out_b) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ __launch_bounds__(64) void k_bn_finalize(const float* __restrict__ partial, int nb, const float* __restrict__ x,
+                                                    int64_t V, int C, float* __restrict__ mean, float* __restrict__ var) {
+  const int c = blockIdx.x;
+  const int lane = threadIdx.x;
   double s1 = 0.0, s2 = 0.0;
-  for (int b = 0; b < nb; ++b) {
+  for (int b = lane; b < nb; b += 64) {
     s1 += (double)partial[(int64_t)b * 2 * C + c];
     s2 += (double)partial[(int64_t)b * 2 * C + C + c];
   }
-  out_a[c] = (float)s1;
-  out_b[c] = (float)s2;
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  if (lane == 0) {
+    const double m = s1 / (double)V;
+    double v = s2 / (double)V - m * m;
+    if (v < 0.0) v = 0.0;
+    mean[c] = (float)((double)x[c] + m);
+    var[c] = (float)v;
+  }
+}
+
+__global__ __launch_bounds__(64) void k_sum_partials(const float* __restrict__ partial, int nb, int C,
+                                                     float* __restrict__ out_a, float* __restrict__ out_b) {
+  const int c = blockIdx.x;
+  const int lane = threadIdx.x;
+  double s1 = 0.0, s2 = 0.0;
+  for (int b = lane; b < nb; b += 64) {
+    s1 += (double)partial[(int64_t)b * 2 * C + c];
+    s2 += (double)partial[(int64_t)b * 2 * C + C + c];
+  }
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  if (lane == 0) {
+    out_a[c] = (float)s1;
+    out_b[c] = (float)s2;
+  }
 }
 
 static int check_vc(const char* who, int64_t V, int32_t C) {
@@ -138,7 +153,7 @@ extern "C" int lt_bn_stats(const float* x, int64_t V, int32_t C, void* ws, int64
   hipLaunchKernelGGL(k_col_partial<StatsOp>, dim3(nb), dim3(BN_BLOCK), (size_t)rpi * 2 * C * 4, stream, op, V, C,
                      (float*)ws);
   LT_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_bn_finalize, dim3(lt_cdiv(C, 64)), dim3(64), 0, stream, (const float*)ws, nb, x, V, C, mean, var);
+  hipLaunchKernelGGL(k_bn_finalize, dim3(C), dim3(64), 0, stream, (const float*)ws, nb, x, V, C, mean, var);
   LT_LAUNCH_CHECK();
   return LT_OK;
 }
@@ -195,7 +210,7 @@ extern "C" int lt_bn_bwd_reduce(const float* dy, const float* x, const float* y,
   hipLaunchKernelGGL(k_col_partial<BwdOp>, dim3(nb), dim3(BN_BLOCK), (size_t)rpi * 2 * C * 4, stream, op, V, C,
                      (float*)ws);
   LT_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_sum_partials, dim3(lt_cdiv(C, 64)), dim3(64), 0, stream, (const float*)ws, nb, C, sum_g, sum_gx);
+  hipLaunchKernelGGL(k_sum_partials, dim3(C), dim3(64), 0, stream, (const float*)ws, nb, C, sum_g, sum_gx);
   LT_LAUNCH_CHECK();
   return LT_OK;
 }

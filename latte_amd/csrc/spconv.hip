@@ -170,13 +170,16 @@ __global__ __launch_bounds__(256) void k_spconv_vec(ConvArgs a) {
 #pragma unroll
         for (int jj = 0; jj < LT_JB; ++jj) {
           if (jj < jb) {
+            // t outermost: consecutive MFMAs hit different accumulators (a dependent 16x16x4 needs 40 cycles, an
+            // independent one issues every 32); the sum order per accumulator is unchanged (t ascending)
+            f32x4 b[NT];
 #pragma unroll
-            for (int n = 0; n < NT; ++n) {
-              const f32x4 b = reinterpret_cast<const f32x4*>(s_w)[(jj * NT + n) * 64 + lane];
-              acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[jj].x, b.x, acc[n], 0, 0, 0);
-              acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[jj].y, b.y, acc[n], 0, 0, 0);
-              acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[jj].z, b.z, acc[n], 0, 0, 0);
-              acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[jj].w, b.w, acc[n], 0, 0, 0);
+            for (int n = 0; n < NT; ++n) b[n] = reinterpret_cast<const f32x4*>(s_w)[(jj * NT + n) * 64 + lane];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+#pragma unroll
+              for (int n = 0; n < NT; ++n)
+                acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[jj][t], b[n][t], acc[n], 0, 0, 0);
             }
           }
         }

@@ -53,6 +53,8 @@ class KernelMap:
         self.submanifold = submanifold  # stride 1, odd kernel: results[K-1-k] is its own reverse table
         self._rev = None
         self._pairs = None
+        self._order = None
+        self._rev_order = None
 
     @property
     def K(self):
@@ -62,6 +64,17 @@ class KernelMap:
         if self._rev is None:
             self._rev = ops.kmap_reverse(self.results, self.n_in)
         return self._rev
+
+    def order(self) -> torch.Tensor:
+        """mask-sorted processing order of `results` rows (see lt_kmap_order)."""
+        if self._order is None:
+            self._order = ops.kmap_order(self.results)
+        return self._order
+
+    def reverse_order(self) -> torch.Tensor:
+        if self._rev_order is None:
+            self._rev_order = ops.kmap_order(self.reverse())
+        return self._rev_order
 
     def pairs(self):
         if self._pairs is None:
@@ -84,8 +97,11 @@ class _SparseConv(Function):
         w = weight if weight.dim() == 3 else weight.unsqueeze(0)
         cout = w.shape[2]
         packed = ops.pack_weights(w, 0)
-        nbr = kmap.reverse() if transposed else kmap.results
-        out = ops.spconv(feats, packed, nbr, cout)
+        if transposed:
+            nbr, order = kmap.reverse(), kmap.reverse_order()
+        else:
+            nbr, order = kmap.results, kmap.order()
+        out = ops.spconv(feats, packed, nbr, cout, order=order)
         ctx.kmap, ctx.transposed = kmap, transposed
         ctx.save_for_backward(feats, weight)
         return out
@@ -100,11 +116,11 @@ class _SparseConv(Function):
         if ctx.needs_input_grad[0]:
             cin = w.shape[1]
             if kmap.submanifold and not transposed:
-                gfeats = ops.spconv(gout, ops.pack_weights(w, 2), kmap.results, cin)
+                gfeats = ops.spconv(gout, ops.pack_weights(w, 2), kmap.results, cin, order=kmap.order())
             elif not transposed:
-                gfeats = ops.spconv(gout, ops.pack_weights(w, 1), kmap.reverse(), cin)
+                gfeats = ops.spconv(gout, ops.pack_weights(w, 1), kmap.reverse(), cin, order=kmap.reverse_order())
             else:
-                gfeats = ops.spconv(gout, ops.pack_weights(w, 1), kmap.results, cin)
+                gfeats = ops.spconv(gout, ops.pack_weights(w, 1), kmap.results, cin, order=kmap.order())
         if ctx.needs_input_grad[1]:
             # dW is only reached when TRAIN.UPDATE_PARAMS == "all" (latte/common/utils/ema_util.py:44-71); the
             # shipped Latte configs train norm layers only.  Device-side torch ops over the pair list (not HIP yet).

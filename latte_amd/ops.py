@@ -13,7 +13,7 @@ from . import _lib
 
 __all__ = [
     "sphash", "HashTable", "sphashquery", "spcount", "unique_sorted", "pack_xyz_keys", "downsample_coords",
-    "kmap_build", "kmap_pairs", "kmap_reverse", "pack_weights", "spconv", "bn_stats", "bn_apply",
+    "kmap_build", "kmap_pairs", "kmap_reverse", "kmap_order", "pack_weights", "spconv", "bn_stats", "bn_apply",
     "bn_bwd", "voxelize_fwd", "voxelize_bwd", "calc_ti_weights", "devoxelize_fwd", "devoxelize_bwd",
 ]
 
@@ -155,6 +155,17 @@ def kmap_reverse(results: torch.Tensor, Vin: int) -> torch.Tensor:
     return rev
 
 
+def kmap_order(table: torch.Tensor) -> torch.Tensor:
+    """Row processing order of a neighbour table [K,V] for spconv (rows sorted by their neighbour mask)."""
+    table = _chk(table, torch.int32, "kmap_order table")
+    K, V = table.shape
+    lib = _lib.load()
+    ws = _ws(lib.lt_kmap_order_workspace_bytes(V), table.device)
+    order = torch.empty(V, dtype=torch.int32, device=table.device)
+    _lib.call("lt_kmap_order", _p(table), K, V, _p(ws), ws.numel(), _p(order), _stream())
+    return order
+
+
 # ------------------------------------------------------------------ sparse conv
 def pack_weights(weight: torch.Tensor, mode: int = 0) -> torch.Tensor:
     """weight [K,Cin,Cout] (or [Cin,Cout]) fp32 -> MFMA-fragment order (see spconv.hip)."""
@@ -165,6 +176,13 @@ def pack_weights(weight: torch.Tensor, mode: int = 0) -> torch.Tensor:
     packed = torch.empty(K * Cin * Cout, dtype=torch.float32, device=w.device)
     _lib.call("lt_spconv_pack_weights", _p(w), K, Cin, Cout, int(mode), _p(packed), _stream())
     return packed
+
+
+# bench.py's kernel timer: when a list, every spconv launch appends (start event, end event, Cin, Cout, K, Vout).
+# Events are recorded on torch's current stream, which is the stream the kernel is launched on.
+CONV_TRACE = None
+# bench.py's flop counter (untimed pass): when a list, every spconv call appends its pair count (device scalar).
+CONV_PAIRS = None
 
 
 def spconv(feats: torch.Tensor, packed: torch.Tensor, nbr: torch.Tensor, cout: int,
@@ -181,8 +199,16 @@ def spconv(feats: torch.Tensor, packed: torch.Tensor, nbr: torch.Tensor, cout: i
         order = _chk(order, torch.int32, "spconv order")
         assert order.numel() == Vout
     out = torch.empty((Vout, cout), dtype=torch.float32, device=feats.device)
+    if CONV_TRACE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _lib.call("lt_spconv_fwd", _p(feats), _p(packed), _p(nbr), _p(order), _p(out), Vin, Vout, Cin, int(cout), K,
               _stream())
+    if CONV_TRACE is not None:
+        e1.record()
+        CONV_TRACE.append((e0, e1, Cin, int(cout), K, Vout))
+    if CONV_PAIRS is not None:
+        CONV_PAIRS.append((nbr >= 0).sum())
     return out
 
 

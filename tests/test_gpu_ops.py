@@ -155,6 +155,26 @@ def test_spconv_order_permutation_is_result_invariant(scans_small):
     assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("ks,stride", [(3, 1), (2, 2)])
+def test_kmap_order_is_stable_mask_sort(scans_small, ks, stride):
+    from latte_amd import ops
+    c = scans_small["coords"]
+    _, _, out_coords, res = ts_ref.build_kmap(c, 1, ks, stride)
+    resd = dev(res, torch.int32)
+    for table in (resd, ops.kmap_reverse(resd, c.shape[0])):
+        t = table.cpu().numpy()
+        K = t.shape[0]
+        mask = ((t >= 0).astype(np.int64) << np.arange(K)[:, None]).sum(0)
+        want = np.argsort(mask, kind="stable")
+        got = ops.kmap_order(table).cpu().numpy()
+        assert np.array_equal(got, want)
+    # the order never changes a result bit
+    g = torch.Generator().manual_seed(9)
+    feats = torch.randn(c.shape[0], 32, generator=g).cuda()
+    pw = ops.pack_weights((torch.randn(res.shape[0], 32, 32, generator=g) / 30).cuda(), 0)
+    assert torch.equal(ops.spconv(feats, pw, resd, 32), ops.spconv(feats, pw, resd, 32, order=ops.kmap_order(resd)))
+
+
 @pytest.mark.parametrize("V,C", [(2, 32), (37, 32), (5000, 96), (20000, 256)])
 @pytest.mark.parametrize("relu,res", [(False, False), (True, False), (True, True)])
 def test_batchnorm_fwd_bwd_matches_torch(V, C, relu, res):

@@ -1,0 +1,121 @@
+#!/usr/bin/env python3
+"""Sparse-conv micro-benchmark (BASELINE.json configs[4]): one 3^3 submanifold conv over ~1M synthetic LiDAR voxels,
+Cin = Cout in {16..256}, timed with HIP events on the launch stream; reports useful TFLOP/s (2*M*Cin*Cout) against the
+fp32 MFMA peak and the gathered bytes against HBM.
+
+  python tools/conv_bench.py [--scans 32] [--points 34816] [--channels 32,64,96,128,256] [--order none|mask|morton]
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scans", type=int, default=32)
+    ap.add_argument("--points", type=int, default=34816)
+    ap.add_argument("--channels", default="16,32,64,96,128,256")
+    ap.add_argument("--stride", type=int, default=1, help="tensor stride of the level the conv runs on (1,2,4,8,16)")
+    ap.add_argument("--order", default="auto", help="row processing order: auto (library default) | none | mask | morton")
+    ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--full360", action="store_true", default=True)
+    ap.add_argument("--out", default=None)
+    args = ap.parse_args()
+
+    import torch
+    from latte_amd import ops, synth
+    from latte_amd import functional as LF
+    from latte_amd.quantize import quantize_scan_gpu
+    from latte_amd import sparse_modules as spnn
+    from latte_amd.tensor import SparseTensor
+    from latte_amd.point_voxel import initial_voxelize
+    from latte_amd.tensor import PointTensor
+
+    dev = torch.device("cuda", 0)
+    coords = []
+    for b in range(args.scans):
+        p, i = synth.make_scan(args.points, b, beams=32, full_360=True)
+        c, f, _, _ = quantize_scan_gpu(torch.from_numpy(p).to(dev), torch.from_numpy(i).to(dev))
+        coords.append(torch.cat([c, torch.full((c.shape[0], 1), b, dtype=torch.int32, device=dev)], 1))
+    C4 = torch.cat(coords, 0)
+    z = PointTensor(torch.zeros(C4.shape[0], 4, device=dev), C4.float())
+    x = initial_voxelize(z, 0.05, 0.05)  # hash-ordered voxels, as in the network
+    s = 1
+    while s < args.stride:  # walk down the U-Net's coordinate pyramid
+        _, oc = spnn.build_kernel_map(x, 2, 2, 1)
+        nx = SparseTensor(torch.zeros(oc.shape[0], 4, device=dev), oc, 2 * s)
+        nx.cmaps, nx.kmaps = x.cmaps, x.kmaps
+        nx.cmaps[nx.stride] = oc
+        x, s = nx, 2 * s
+    kmap, _ = spnn.build_kernel_map(x, 3, 1, 1)
+    nbr = kmap.results
+    V = nbr.shape[1]
+    M = int((nbr >= 0).sum())
+    order = None
+    if args.order == "none":
+        act = (torch.cat([nbr, torch.full((nbr.shape[0], (V + 15) // 16 * 16 - V), -1, dtype=nbr.dtype, device=dev)], 1)
+               .view(nbr.shape[0], -1, 16) >= 0).any(2).sum().item()
+        print(f"order=none: issued row-offsets {act * 16} vs pairs {M} -> MFMA utilisation {M / (act * 16):.3f}")
+    if args.order == "auto":
+        order = kmap.order() if hasattr(kmap, "order") else None
+    elif args.order != "none":
+        K = nbr.shape[0]
+        mask = ((nbr >= 0).long() << torch.arange(K, device=dev).view(-1, 1)).sum(0)
+        c = x.coords.long()
+        def spread(v):
+            v = v & 0x3FF
+            v = (v | (v << 16)) & 0x30000FF
+            v = (v | (v << 8)) & 0x300F00F
+            v = (v | (v << 4)) & 0x30C30C3
+            v = (v | (v << 2)) & 0x9249249
+            return v
+        q = c[:, :3] // max(args.stride, 1)
+        mort = (c[:, 3] << 32) | (spread(q[:, 0]) << 2) | (spread(q[:, 1]) << 1) | spread(q[:, 2])
+        if args.order == "mask":
+            key = mask
+        elif args.order == "morton":
+            key = mort
+        elif args.order.startswith("block"):  # block<bits>: morton >> bits, then mask
+            bits = int(args.order[5:])
+            key = ((mort >> bits) << 27) | mask
+        else:
+            raise SystemExit("unknown order")
+        order = torch.argsort(key, stable=True).to(torch.int32)
+        # strip statistics: MFMA work the kernel issues = sum over 16-row strips of (#offsets with any neighbour)
+        nb = nbr[:, order.long()]
+        Vp = (V + 15) // 16 * 16
+        pad = torch.full((K, Vp - V), -1, dtype=nbr.dtype, device=dev)
+        act = (torch.cat([nb, pad], 1).view(K, -1, 16) >= 0).any(2).sum().item()
+        print(f"order={args.order}: issued row-offsets {act * 16} vs pairs {M} -> MFMA utilisation {M / (act * 16):.3f}")
+    rows = []
+    for C in [int(v) for v in args.channels.split(",")]:
+        feats = torch.randn(V, C, device=dev)
+        w = torch.randn(27, C, C, device=dev) * 0.05
+        packed = ops.pack_weights(w, 0)
+        for _ in range(2):
+            out = ops.spconv(feats, packed, nbr, C, order=order)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.reps):
+            out = ops.spconv(feats, packed, nbr, C, order=order)
+        e1.record()
+        torch.cuda.synchronize()
+        us = 1e3 * e0.elapsed_time(e1) / args.reps
+        flops = 2.0 * M * C * C
+        comp_bytes = 4.0 * (V * C * 2 + 27 * C * C) + 4.0 * 27 * V
+        rows.append(dict(C=C, V=V, M=M, pairs_per_voxel=round(M / V, 2), us=round(us, 1),
+                         tflops=round(flops / us / 1e6, 2), frac_f32_mfma=round(flops / us / 1e6 / 157.3, 4),
+                         compulsory_GBs=round(comp_bytes / us / 1e3, 1), gathered_GBs=round(4.0 * M * C / us / 1e3, 1)))
+        print(json.dumps(rows[-1]), flush=True)
+    if args.out:
+        json.dump(dict(args=vars(args), rows=rows), open(args.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
