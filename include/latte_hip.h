@@ -89,6 +89,15 @@ int64_t lt_kmap_order_workspace_bytes(int64_t V);
 int lt_kmap_order(const int32_t* table, int32_t K, int64_t V, void* ws, int64_t ws_bytes, int32_t* order,
                   lt_stream_t stream);
 
+/* Conv plan of a neighbour table [K,V]: the mask-sorted row order plus the table re-laid out per 64-row tile and one
+ * 64-bit row mask per (tile, offset) -- what lt_spconv_plan_fwd consumes.  Built once per kernel map, shared by every
+ * conv (forward and backward) that uses the map.  `plan` is a caller-owned buffer of lt_kmap_plan_bytes(K,V) bytes,
+ * 16-byte aligned.  No counterpart in torchsparse.  No sync. */
+int64_t lt_kmap_plan_bytes(int32_t K, int64_t V);
+int64_t lt_kmap_plan_workspace_bytes(int64_t V);
+int lt_kmap_plan(const int32_t* table, int32_t K, int64_t V, void* ws, int64_t ws_bytes, void* plan, int64_t plan_bytes,
+                 lt_stream_t stream);
+
 /* ------------------------------------------------------------------ sparse convolution
  * spnn.Conv3d forward / backward-input (basic_blocks.py:17,34,51,58,68; spvcnn.py:30,32):
  *   out[o,:] = sum_k in[nbr[k,o],:] @ Wk      (rows with nbr<0 contribute nothing)
@@ -105,10 +114,11 @@ int lt_spconv_pack_weights(const float* W, int32_t K, int32_t Cin, int32_t Cout,
                            lt_stream_t stream);
 int lt_spconv_fwd(const float* in, const float* packed, const int32_t* nbr, const int32_t* order, float* out,
                   int64_t Vin, int64_t Vout, int32_t Cin, int32_t Cout, int32_t K, lt_stream_t stream);
-/* dW[k] = sum over pairs in[nbr[k,o],:]^T (x) dout[o,:]   (only needed when TRAIN.UPDATE_PARAMS == "all") */
-int lt_spconv_bwd_weight(const float* in, const float* dout, const int32_t* nbr, float* dW, int64_t Vin,
-                         int64_t Vout, int32_t Cin, int32_t Cout, int32_t K, lt_stream_t stream);
-
+/* Same product as lt_spconv_fwd through a plan (lt_kmap_plan) of the [K,Vout] table: only the offsets active in a
+ * 64-row tile are visited, weights stream global->LDS by LDS-DMA one stage ahead of the MFMAs.  Cin % 16 == 0 and
+ * Cout % 16 == 0.  Bitwise equal to lt_spconv_fwd. */
+int lt_spconv_plan_fwd(const float* in, const float* packed, const void* plan, float* out, int64_t Vin, int64_t Vout,
+                       int32_t Cin, int32_t Cout, int32_t K, lt_stream_t stream);
 /* ------------------------------------------------------------------ BatchNorm(batch stats)+ReLU+residual
  * spnn.BatchNorm + spnn.ReLU + skip add (basic_blocks.py:22-23,56-57,64,69,72,75); TTA forces batch
  * statistics (latte/common/utils/ema_util.py:26-29).  var is the biased variance. */

@@ -63,6 +63,29 @@ static inline int64_t lt_pow2_ge(int64_t x) {
   return p;
 }
 
+// conv plan of a neighbour table [K,V] (built by lt_kmap_plan, consumed by lt_spconv_plan_fwd): one caller-owned buffer
+//   order [V] int32 | tnbr [T][K][64] int32 | tmask [T][K] uint64,   T = ceil(V/64), pieces 256-B aligned
+struct LtPlanView {
+  int* order;
+  int* tnbr;
+  unsigned long long* tmask;
+  int64_t bytes;
+};
+static inline LtPlanView lt_plan_view(void* mem, int K, int64_t V) {
+  const int64_t T = (V + 63) / 64;
+  char* p = (char*)mem;
+  LtPlanView v;
+  int64_t off = 0;
+  v.order = (int*)(p + off);
+  off += lt_align_up((V > 0 ? V : 1) * 4, 256);
+  v.tnbr = (int*)(p + off);
+  off += lt_align_up((T > 0 ? T : 1) * K * 64 * 4, 256);
+  v.tmask = (unsigned long long*)(p + off);
+  off += lt_align_up((T > 0 ? T : 1) * K * 8, 256);
+  v.bytes = off;
+  return v;
+}
+
 // ---- device helpers -------------------------------------------------------
 #define LT_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
 

@@ -282,3 +282,40 @@ extern "C" int lt_kmap_order(const int32_t* table, int32_t K, int64_t V, void* w
   LT_CHECK_HIP(rocprim::radix_sort_pairs(tmp, sbs, masks, smasks, iota, order, (size_t)V, 0, (unsigned)K, stream));
   return LT_OK;
 }
+
+// ---------------------------------------------------------------- conv plan (tile layout of a neighbour table)
+// one 256-thread block per 64-row tile: wave w handles offsets k = w, w+4, ...; lane i = row i of the tile
+__global__ __launch_bounds__(256) void k_plan_tiles(const int* __restrict__ table, int K, int64_t V,
+                                                    const int* __restrict__ order, int* __restrict__ tnbr,
+                                                    unsigned long long* __restrict__ tmask) {
+  const int64_t tile = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t slot = tile * 64 + lane;
+  const int row = slot < V ? order[slot] : -1;
+  for (int k = wave; k < K; k += 4) {
+    const int v = row >= 0 ? table[(int64_t)k * V + row] : -1;
+    tnbr[(tile * K + k) * 64 + lane] = v;
+    const unsigned long long m = __ballot(v >= 0);
+    if (lane == 0) tmask[tile * K + k] = m;
+  }
+}
+
+extern "C" int64_t lt_kmap_plan_bytes(int32_t K, int64_t V) { return lt_plan_view(nullptr, K, V).bytes; }
+extern "C" int64_t lt_kmap_plan_workspace_bytes(int64_t V) { return lt_kmap_order_workspace_bytes(V); }
+
+extern "C" int lt_kmap_plan(const int32_t* table, int32_t K, int64_t V, void* ws, int64_t ws_bytes, void* plan,
+                            int64_t plan_bytes, hipStream_t stream) {
+  LT_REQUIRE(K >= 1 && K <= 32 && V >= 0 && V < INT_MAX, LT_ERR_ARG, "lt_kmap_plan: bad sizes (K=%d)", K);
+  if (V == 0) return LT_OK;
+  LT_REQUIRE(table && ws && plan, LT_ERR_ARG, "lt_kmap_plan: null pointer");
+  LT_REQUIRE(((uintptr_t)plan & 15) == 0, LT_ERR_ARG, "lt_kmap_plan: plan must be 16-byte aligned");
+  LtPlanView pv = lt_plan_view(plan, K, V);
+  LT_REQUIRE(plan_bytes >= pv.bytes, LT_ERR_WORKSPACE, "lt_kmap_plan: plan needs %lld bytes, got %lld",
+             (long long)pv.bytes, (long long)plan_bytes);
+  int rc = lt_kmap_order(table, K, V, ws, ws_bytes, pv.order, stream);
+  if (rc) return rc;
+  const int64_t T = (V + 63) / 64;
+  hipLaunchKernelGGL(k_plan_tiles, dim3((unsigned)T), dim3(256), 0, stream, table, K, V, pv.order, pv.tnbr, pv.tmask);
+  LT_LAUNCH_CHECK();
+  return LT_OK;
+}

@@ -255,6 +255,227 @@ __global__ __launch_bounds__(256) void k_spconv_scalar(ConvArgs a) {
   }
 }
 
+// =====================================================================================================
+// Planned kernel: the hot path.  Works on a "plan" of the neighbour table (lt_kmap_plan, kmap.hip): rows sorted by
+// neighbour mask, the table re-laid out per 64-row tile ([tile][k][64], coalesced) and one 64-bit row mask per
+// (tile, k).  Differences to k_spconv_vec:
+//  * only the offsets that are active in the tile are visited (compacted list), 16-row strips without a neighbour at
+//    k skip that k's MFMAs;
+//  * the weights of the next stage are copied global -> LDS by the LDS-DMA engine (global_load_lds_dwordx4, the packed
+//    fragment image is lane-linear) while the MFMAs of the current stage run: two LDS buffers, ONE barrier per stage;
+//    the gathered A rows of the next stage are prefetched into a second register set at the same point;
+//  * a stage is UB "slabs" (= one offset x one 16-channel group of Cin), so narrow layers still get >= 16 KiB stages.
+// Every output element is still one k-ascending, channel-ascending fmaf chain -> bitwise equal to k_spconv_vec.
+struct PlanArgs {
+  const float* in;
+  const float* packed;
+  const int* tnbr;                    // [T][K][64]
+  const unsigned long long* tmask;    // [T][K]
+  const int* order;                   // [Vout]
+  float* out;
+  int Vin, Vout, Cin, Cout, K;
+};
+
+typedef __attribute__((address_space(3))) void* lt_lds_ptr;
+typedef __attribute__((address_space(1))) const void* lt_glb_ptr;
+
+template <int NT, int UB, int SR>
+__global__ __launch_bounds__(256) void k_spconv_plan(PlanArgs a) {
+  constexpr int WB = UB * NT * 256;  // floats per weight buffer (UB*NT fragments of 1 KiB)
+  constexpr int TMW = LT_TM * SR;    // output rows per workgroup: SR plan tiles, wave w owns strip w of each
+  // one LDS object (a second one beside an LDS-DMA target makes hipcc drain vmcnt before every ds_read)
+  __shared__ __attribute__((aligned(16))) float smem[2 * WB + LT_KMAX * TMW + TMW + LT_KMAX * (1 + 2 * SR) + 4];
+  float* s_w = smem;
+  int* s_nbr = reinterpret_cast<int*>(smem + 2 * WB);        // [nact][TMW] (compacted offsets)
+  int* s_rows = s_nbr + LT_KMAX * TMW;                         // [TMW]
+  int* s_klist = s_rows + TMW;                                 // [32] active offsets, ascending
+  unsigned int* s_km = reinterpret_cast<unsigned int*>(s_klist + LT_KMAX);  // [32][SR][2] their row masks
+  int* s_nact = reinterpret_cast<int*>(s_km + 2 * SR * LT_KMAX);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  const int64_t tile0 = (int64_t)blockIdx.x * SR;              // first plan tile of this workgroup
+  const int64_t T = ((int64_t)a.Vout + LT_TM - 1) / LT_TM;
+  const int J = a.Cin / 16, NTt = a.Cout / 16, nt0 = blockIdx.y * NT;
+
+  if (wave == 0) {
+    unsigned long long m[SR];
+    unsigned long long any = 0ull;
+#pragma unroll
+    for (int h = 0; h < SR; ++h) {
+      m[h] = 0ull;
+      if (lane < a.K && tile0 + h < T) m[h] = a.tmask[(tile0 + h) * a.K + lane];
+      any |= m[h];
+    }
+    const unsigned long long bal = __ballot(any != 0ull);
+    if (any != 0ull) {
+      const int pos = __popcll(bal & ((1ull << lane) - 1ull));
+      s_klist[pos] = lane;
+#pragma unroll
+      for (int h = 0; h < SR; ++h) {
+        s_km[(pos * SR + h) * 2] = (unsigned int)m[h];
+        s_km[(pos * SR + h) * 2 + 1] = (unsigned int)(m[h] >> 32);
+      }
+    }
+    if (lane == 0) *s_nact = __popcll(bal);
+  } else if (wave <= SR) {
+    const int h = wave - 1;
+    const int64_t slot = (tile0 + h) * LT_TM + lane;
+    s_rows[h * LT_TM + lane] = slot < a.Vout ? a.order[slot] : -1;
+  }
+  __syncthreads();
+  const int nact = *s_nact;
+  for (int e = tid; e < nact * TMW; e += 256) {
+    const int ki = e / TMW, i = e - ki * TMW;
+    const int h = i >> 6;
+    int v = -1;
+    if (tile0 + h < T) v = a.tnbr[((tile0 + h) * a.K + s_klist[ki]) * LT_TM + (i & 63)];
+    if (v >= a.Vin) v = -1;  // defensive: never gather out of bounds
+    s_nbr[e] = v;
+  }
+  __syncthreads();
+
+  f32x4 acc[SR][NT];
+#pragma unroll
+  for (int h = 0; h < SR; ++h)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[h][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int U = nact * J;                 // slabs of this workgroup, (ki, j) with j fastest
+  const int S = (U + UB - 1) / UB;        // stages
+  const float* in_q = a.in + 4 * q;
+
+  // 16-bit row mask of this wave's strip of plan tile h at compacted offset ki
+  auto strip_mask = [&](int ki, int h) -> unsigned int {
+    return (s_km[(ki * SR + h) * 2 + (wave >> 1)] >> (16 * (wave & 1))) & 0xFFFFu;
+  };
+
+  // issue stage s: LDS-DMA of its weight fragments into buffer `buf`, gather of its A fragments into `av`
+  auto issue = [&](int s, int buf, f32x4 (&av)[UB][SR]) {
+    const int u0 = s * UB;
+    const int nu = (U - u0) < UB ? (U - u0) : UB;
+    // fragment f = uu*NT + n of the stage; wave w copies f = w, w+4, ...
+    for (int f = wave; f < nu * NT; f += 4) {
+      const int uu = f / NT, n = f - uu * NT;
+      const int u = u0 + uu;
+      const int ki = u / J, j = u - ki * J;
+      const int k = s_klist[ki];
+      const float* g = a.packed + ((((int64_t)k * J + j) * NTt + nt0 + n) * 64 + lane) * 4;
+      __builtin_amdgcn_global_load_lds((lt_glb_ptr)g, (lt_lds_ptr)(s_w + buf * WB + f * 256), 16, 0, 0);
+    }
+#pragma unroll
+    for (int uu = 0; uu < UB; ++uu) {
+#pragma unroll
+      for (int h = 0; h < SR; ++h) {
+        av[uu][h] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (uu < nu) {
+          const int u = u0 + uu;
+          const int ki = u / J, j = u - ki * J;
+          if (strip_mask(ki, h) != 0u) {
+            const int src = s_nbr[ki * TMW + h * LT_TM + 16 * wave + r];
+            if (src >= 0) av[uu][h] = *reinterpret_cast<const f32x4*>(in_q + (int64_t)src * a.Cin + 16 * j);
+          }
+        }
+      }
+    }
+  };
+  auto compute = [&](int s, int buf, const f32x4 (&av)[UB][SR]) {
+    const int u0 = s * UB;
+    const int nu = (U - u0) < UB ? (U - u0) : UB;
+#pragma unroll
+    for (int uu = 0; uu < UB; ++uu) {
+      if (uu < nu) {
+        const int ki = (u0 + uu) / J;
+        bool on[SR];
+        bool any = false;
+#pragma unroll
+        for (int h = 0; h < SR; ++h) { on[h] = strip_mask(ki, h) != 0u; any = any || on[h]; }
+        if (any) {  // wave-uniform
+          f32x4 b[NT];
+#pragma unroll
+          for (int n = 0; n < NT; ++n)
+            b[n] = reinterpret_cast<const f32x4*>(s_w + buf * WB)[(uu * NT + n) * 64 + lane];
+#pragma unroll
+          for (int h = 0; h < SR; ++h) {
+            if (on[h]) {
+              // t outermost: consecutive MFMAs hit different accumulators; per accumulator the order stays t ascending
+#pragma unroll
+              for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                  acc[h][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[uu][h][t], b[n][t], acc[h][n], 0, 0, 0);
+              }
+            }
+          }
+        }
+      }
+    }
+  };
+
+  f32x4 avA[UB][SR], avB[UB][SR];
+  if (S > 0) issue(0, 0, avA);
+  for (int s = 0; s < S; s += 2) {
+    __syncthreads();  // stage s has landed (the compiler drains vmcnt here); nobody reads buffer 1 any more
+    if (s + 1 < S) issue(s + 1, 1, avB);
+    compute(s, 0, avA);
+    if (s + 1 >= S) break;
+    __syncthreads();
+    if (s + 2 < S) issue(s + 2, 0, avA);
+    compute(s + 1, 1, avB);
+  }
+
+  // epilogue: C/D layout col = lane&15, row = 4*(lane>>4) + reg
+#pragma unroll
+  for (int h = 0; h < SR; ++h) {
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int row = s_rows[h * LT_TM + 16 * wave + 4 * q + reg];
+      if (row >= 0) {
+        float* o = a.out + (int64_t)row * a.Cout + 16 * nt0 + r;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) o[16 * n] = acc[h][n][reg];
+      }
+    }
+  }
+}
+
+template <int NT, int UB>
+static int launch_plan(const PlanArgs& a, hipStream_t stream) {
+  const int64_t T = ((int64_t)a.Vout + LT_TM - 1) / LT_TM;
+  const int64_t cb = a.Cout / (16 * NT);
+  // two plan tiles per workgroup (half the weight traffic per flop) once the grid still fills the chip a few times over
+  if (T * cb >= 2 * 4 * 256) {
+    dim3 grid((unsigned)((T + 1) / 2), (unsigned)cb);
+    hipLaunchKernelGGL((k_spconv_plan<NT, UB, 2>), grid, dim3(256), 0, stream, a);
+  } else {
+    dim3 grid((unsigned)T, (unsigned)cb);
+    hipLaunchKernelGGL((k_spconv_plan<NT, UB, 1>), grid, dim3(256), 0, stream, a);
+  }
+  LT_LAUNCH_CHECK();
+  return LT_OK;
+}
+
+extern "C" int lt_spconv_plan_fwd(const float* in, const float* packed, const void* plan, float* out, int64_t Vin,
+                                  int64_t Vout, int32_t Cin, int32_t Cout, int32_t K, hipStream_t stream) {
+  LT_REQUIRE(Vin >= 0 && Vout >= 0 && Vin < INT32_MAX && Vout < INT32_MAX, LT_ERR_RANGE, "lt_spconv_plan_fwd: bad row counts");
+  LT_REQUIRE(K >= 1 && K <= LT_KMAX, LT_ERR_ARG, "lt_spconv_plan_fwd: kernel volume %d not in [1,%d]", K, LT_KMAX);
+  LT_REQUIRE(Cin >= 16 && Cin % 16 == 0, LT_ERR_ARG, "lt_spconv_plan_fwd: Cin=%d must be a multiple of 16", Cin);
+  LT_REQUIRE(Cout >= 16 && Cout % 16 == 0, LT_ERR_ARG, "lt_spconv_plan_fwd: Cout=%d must be a multiple of 16", Cout);
+  if (Vout == 0) return LT_OK;
+  LT_REQUIRE(packed && plan && out && (Vin == 0 || in), LT_ERR_ARG, "lt_spconv_plan_fwd: null pointer");
+  LT_REQUIRE(((uintptr_t)plan & 15) == 0, LT_ERR_ARG, "lt_spconv_plan_fwd: plan must be 16-byte aligned");
+  LtPlanView pv = lt_plan_view(const_cast<void*>(plan), K, Vout);
+  PlanArgs a{in, packed, pv.tnbr, pv.tmask, pv.order, out, (int)Vin, (int)Vout, Cin, Cout, K};
+  const int ntt = Cout / 16;
+  if (ntt % 8 == 0) return launch_plan<8, 2>(a, stream);
+  if (ntt % 6 == 0) return launch_plan<6, 2>(a, stream);
+  if (ntt % 4 == 0) return launch_plan<4, 4>(a, stream);
+  if (ntt % 3 == 0) return launch_plan<3, 4>(a, stream);
+  if (ntt % 2 == 0) return launch_plan<2, 8>(a, stream);
+  return launch_plan<1, 8>(a, stream);
+}
+
 template <int NT>
 static int launch_conv(const ConvArgs& a, hipStream_t stream) {
   dim3 grid(lt_cdiv(a.Vout, LT_TM), a.Cout / (16 * NT));

@@ -55,6 +55,9 @@ class KernelMap:
         self._pairs = None
         self._order = None
         self._rev_order = None
+        self._plan = None
+        self._rev_plan = None
+        self._npairs = None
 
     @property
     def K(self):
@@ -76,6 +79,17 @@ class KernelMap:
             self._rev_order = ops.kmap_order(self.reverse())
         return self._rev_order
 
+    def plan(self) -> torch.Tensor:
+        """conv plan of `results` (built once, shared by every conv on this map)."""
+        if self._plan is None:
+            self._plan = ops.kmap_plan(self.results)
+        return self._plan
+
+    def reverse_plan(self) -> torch.Tensor:
+        if self._rev_plan is None:
+            self._rev_plan = ops.kmap_plan(self.reverse())
+        return self._rev_plan
+
     def pairs(self):
         if self._pairs is None:
             self._pairs = ops.kmap_pairs(self.results)
@@ -91,17 +105,28 @@ class KernelMap:
         raise IndexError(i)
 
 
+def _run_conv(feats, packed, kmap: KernelMap, use_reverse: bool, cout: int):
+    """out[o] = sum_k feats[table[k,o]] @ E_k over `results` (or the reverse table)."""
+    if ops.CONV_PAIRS is not None:  # bench.py's flop counter (untimed pass)
+        if kmap._npairs is None:
+            kmap._npairs = (kmap.results >= 0).sum()
+        ops.CONV_PAIRS.append(kmap._npairs)
+    if feats.shape[1] % 16 == 0:
+        n_out = kmap.n_in if use_reverse else kmap.n_out
+        plan = kmap.reverse_plan() if use_reverse else kmap.plan()
+        return ops.spconv_plan(feats, packed, plan, kmap.K, n_out, cout)
+    if use_reverse:
+        return ops.spconv(feats, packed, kmap.reverse(), cout, order=kmap.reverse_order())
+    return ops.spconv(feats, packed, kmap.results, cout, order=kmap.order())
+
+
 class _SparseConv(Function):
     @staticmethod
     def forward(ctx, feats, weight, kmap: KernelMap, transposed: bool):
         w = weight if weight.dim() == 3 else weight.unsqueeze(0)
         cout = w.shape[2]
         packed = ops.pack_weights(w, 0)
-        if transposed:
-            nbr, order = kmap.reverse(), kmap.reverse_order()
-        else:
-            nbr, order = kmap.results, kmap.order()
-        out = ops.spconv(feats, packed, nbr, cout, order=order)
+        out = _run_conv(feats, packed, kmap, transposed, cout)
         ctx.kmap, ctx.transposed = kmap, transposed
         ctx.save_for_backward(feats, weight)
         return out
@@ -116,11 +141,11 @@ class _SparseConv(Function):
         if ctx.needs_input_grad[0]:
             cin = w.shape[1]
             if kmap.submanifold and not transposed:
-                gfeats = ops.spconv(gout, ops.pack_weights(w, 2), kmap.results, cin, order=kmap.order())
+                gfeats = _run_conv(gout, ops.pack_weights(w, 2), kmap, False, cin)
             elif not transposed:
-                gfeats = ops.spconv(gout, ops.pack_weights(w, 1), kmap.reverse(), cin, order=kmap.reverse_order())
+                gfeats = _run_conv(gout, ops.pack_weights(w, 1), kmap, True, cin)
             else:
-                gfeats = ops.spconv(gout, ops.pack_weights(w, 1), kmap.results, cin, order=kmap.order())
+                gfeats = _run_conv(gout, ops.pack_weights(w, 1), kmap, False, cin)
         if ctx.needs_input_grad[1]:
             # dW is only reached when TRAIN.UPDATE_PARAMS == "all" (latte/common/utils/ema_util.py:44-71); the
             # shipped Latte configs train norm layers only.  Device-side torch ops over the pair list (not HIP yet).

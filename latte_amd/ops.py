@@ -13,7 +13,7 @@ from . import _lib
 
 __all__ = [
     "sphash", "HashTable", "sphashquery", "spcount", "unique_sorted", "pack_xyz_keys", "downsample_coords",
-    "kmap_build", "kmap_pairs", "kmap_reverse", "kmap_order", "pack_weights", "spconv", "bn_stats", "bn_apply",
+    "kmap_build", "kmap_pairs", "kmap_reverse", "kmap_order", "kmap_plan", "spconv_plan", "pack_weights", "spconv", "bn_stats", "bn_apply",
     "bn_bwd", "voxelize_fwd", "voxelize_bwd", "calc_ti_weights", "devoxelize_fwd", "devoxelize_bwd",
 ]
 
@@ -166,6 +166,17 @@ def kmap_order(table: torch.Tensor) -> torch.Tensor:
     return order
 
 
+def kmap_plan(table: torch.Tensor) -> torch.Tensor:
+    """Conv plan (opaque uint8 buffer) of a neighbour table [K,V]; see lt_kmap_plan."""
+    table = _chk(table, torch.int32, "kmap_plan table")
+    K, V = table.shape
+    lib = _lib.load()
+    ws = _ws(lib.lt_kmap_plan_workspace_bytes(V), table.device)
+    plan = _ws(lib.lt_kmap_plan_bytes(K, V), table.device)
+    _lib.call("lt_kmap_plan", _p(table), K, V, _p(ws), ws.numel(), _p(plan), plan.numel(), _stream())
+    return plan
+
+
 # ------------------------------------------------------------------ sparse conv
 def pack_weights(weight: torch.Tensor, mode: int = 0) -> torch.Tensor:
     """weight [K,Cin,Cout] (or [Cin,Cout]) fp32 -> MFMA-fragment order (see spconv.hip)."""
@@ -207,8 +218,24 @@ def spconv(feats: torch.Tensor, packed: torch.Tensor, nbr: torch.Tensor, cout: i
     if CONV_TRACE is not None:
         e1.record()
         CONV_TRACE.append((e0, e1, Cin, int(cout), K, Vout))
-    if CONV_PAIRS is not None:
-        CONV_PAIRS.append((nbr >= 0).sum())
+    return out
+
+
+def spconv_plan(feats: torch.Tensor, packed: torch.Tensor, plan: torch.Tensor, K: int, Vout: int, cout: int):
+    """spconv through a plan of the [K,Vout] table (the hot path; Cin % 16 == 0)."""
+    feats = _chk(feats, torch.float32, "spconv feats")
+    packed = _chk(packed, torch.float32, "spconv packed")
+    Vin, Cin = feats.shape
+    if packed.numel() != K * Cin * cout:
+        raise ValueError(f"spconv: packed weights have {packed.numel()} floats, expected {K}*{Cin}*{cout}")
+    out = torch.empty((Vout, cout), dtype=torch.float32, device=feats.device)
+    if CONV_TRACE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.call("lt_spconv_plan_fwd", _p(feats), _p(packed), _p(plan), _p(out), Vin, Vout, Cin, int(cout), K, _stream())
+    if CONV_TRACE is not None:
+        e1.record()
+        CONV_TRACE.append((e0, e1, Cin, int(cout), K, Vout))
     return out
 
 

@@ -175,6 +175,50 @@ def test_kmap_order_is_stable_mask_sort(scans_small, ks, stride):
     assert torch.equal(ops.spconv(feats, pw, resd, 32), ops.spconv(feats, pw, resd, 32, order=ops.kmap_order(resd)))
 
 
+@pytest.mark.parametrize("cin,cout", [(16, 16), (32, 32), (32, 64), (96, 96), (128, 96), (192, 128), (384, 256), (48, 48),
+                                      (64, 80)])
+@pytest.mark.parametrize("ks,stride", [(3, 1), (2, 2)])
+def test_spconv_plan_is_bitwise_equal_to_table_kernel(scans_small, cin, cout, ks, stride):
+    """the planned (mask-sorted, LDS-DMA pipelined) kernel must reproduce the plain table kernel bit for bit, on the
+    forward table and on the reverse table (transposed conv / strided backward)"""
+    from latte_amd import ops
+    c = scans_small["coords"]
+    _, _, out_coords, res = ts_ref.build_kmap(c, 1, ks, stride)
+    K = res.shape[0]
+    g = torch.Generator().manual_seed(cin + 7 * cout)
+    w = (torch.randn(K, cin, cout, generator=g) / np.sqrt(K * cin)).cuda()
+    resd = dev(res, torch.int32)
+    feats = torch.randn(c.shape[0], cin, generator=g).cuda()
+    pw = ops.pack_weights(w, 0)
+    a = ops.spconv(feats, pw, resd, cout)
+    b = ops.spconv_plan(feats, pw, ops.kmap_plan(resd), K, resd.shape[1], cout)
+    assert torch.equal(a, b)
+    rev = ops.kmap_reverse(resd, c.shape[0])
+    gout = torch.randn(out_coords.shape[0], cout, generator=g).cuda()
+    pwt = ops.pack_weights(w, 1)
+    a = ops.spconv(gout, pwt, rev, cin)
+    b = ops.spconv_plan(gout, pwt, ops.kmap_plan(rev), K, c.shape[0], cin)
+    assert torch.equal(a, b)
+
+
+def test_spconv_plan_empty_rows_and_ragged_tail():
+    """V not a multiple of 64, rows without any neighbour, offsets without any pair"""
+    from latte_amd import ops
+    g = torch.Generator().manual_seed(21)
+    V, K, C = 131, 27, 32
+    nbr = torch.full((K, V), -1, dtype=torch.int32)
+    nbr[13] = torch.arange(V, dtype=torch.int32)          # centre offset: identity
+    nbr[13, 5] = -1                                          # a row with no neighbour at all
+    nbr[3, 70:] = torch.randint(0, V, (V - 70,), generator=g).int()
+    feats = torch.randn(V, C, generator=g).cuda()
+    pw = ops.pack_weights((torch.randn(K, C, C, generator=g) / 10).cuda(), 0)
+    nd = nbr.cuda()
+    a = ops.spconv(feats, pw, nd, C)
+    b = ops.spconv_plan(feats, pw, ops.kmap_plan(nd), K, V, C)
+    assert torch.equal(a, b)
+    assert float(b[5].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("V,C", [(2, 32), (37, 32), (5000, 96), (20000, 256)])
 @pytest.mark.parametrize("relu,res", [(False, False), (True, False), (True, True)])
 def test_batchnorm_fwd_bwd_matches_torch(V, C, relu, res):

@@ -58,13 +58,16 @@ def main():
     V = nbr.shape[1]
     M = int((nbr >= 0).sum())
     order = None
-    if args.order == "none":
+    plan = ops.kmap_plan(nbr) if args.order == "plan" else None
+    if args.order == "plan":
+        pass
+    elif args.order == "none":
         act = (torch.cat([nbr, torch.full((nbr.shape[0], (V + 15) // 16 * 16 - V), -1, dtype=nbr.dtype, device=dev)], 1)
                .view(nbr.shape[0], -1, 16) >= 0).any(2).sum().item()
         print(f"order=none: issued row-offsets {act * 16} vs pairs {M} -> MFMA utilisation {M / (act * 16):.3f}")
     if args.order == "auto":
         order = kmap.order() if hasattr(kmap, "order") else None
-    elif args.order != "none":
+    elif args.order not in ("none", "plan"):
         K = nbr.shape[0]
         mask = ((nbr >= 0).long() << torch.arange(K, device=dev).view(-1, 1)).sum(0)
         c = x.coords.long()
@@ -98,12 +101,16 @@ def main():
         feats = torch.randn(V, C, device=dev)
         w = torch.randn(27, C, C, device=dev) * 0.05
         packed = ops.pack_weights(w, 0)
+        if plan is not None:
+            run = lambda: ops.spconv_plan(feats, packed, plan, 27, V, C)
+        else:
+            run = lambda: ops.spconv(feats, packed, nbr, C, order=order)
         for _ in range(2):
-            out = ops.spconv(feats, packed, nbr, C, order=order)
+            out = run()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(args.reps):
-            out = ops.spconv(feats, packed, nbr, C, order=order)
+            out = run()
         e1.record()
         torch.cuda.synchronize()
         us = 1e3 * e0.elapsed_time(e1) / args.reps
