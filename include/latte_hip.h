@@ -119,6 +119,10 @@ int lt_spconv_fwd(const float* in, const float* packed, const int32_t* nbr, cons
  * Cout % 16 == 0.  Bitwise equal to lt_spconv_fwd. */
 int lt_spconv_plan_fwd(const float* in, const float* packed, const void* plan, float* out, int64_t Vin, int64_t Vout,
                        int32_t Cin, int32_t Cout, int32_t K, lt_stream_t stream);
+/* the same with an explicit kernel variant (tuning and tests): 0 = default, 1 = LDS-DMA staged kernel,
+ * 100*SR + NTW = register-fed kernel with SR (4|8) 16-row strips per workgroup and NTW (1|2|4) column tiles per wave */
+int lt_spconv_plan_fwd_v(const float* in, const float* packed, const void* plan, float* out, int64_t Vin, int64_t Vout,
+                         int32_t Cin, int32_t Cout, int32_t K, int32_t variant, lt_stream_t stream);
 /* ------------------------------------------------------------------ BatchNorm(batch stats)+ReLU+residual
  * spnn.BatchNorm + spnn.ReLU + skip add (basic_blocks.py:22-23,56-57,64,69,72,75); TTA forces batch
  * statistics (latte/common/utils/ema_util.py:26-29).  var is the biased variance. */

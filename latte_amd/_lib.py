@@ -42,6 +42,7 @@ SIGNATURES = {
     "lt_kmap_plan_workspace_bytes": (I64, [I64]),
     "lt_kmap_plan": (ctypes.c_int, [P, I32, I64, P, I64, P, I64, P]),
     "lt_spconv_plan_fwd": (ctypes.c_int, [P, P, P, P, I64, I64, I32, I32, I32, P]),
+    "lt_spconv_plan_fwd_v": (ctypes.c_int, [P, P, P, P, I64, I64, I32, I32, I32, I32, P]),
     "lt_spconv_packed_floats": (I64, [I32, I32, I32]),
     "lt_spconv_pack_weights": (ctypes.c_int, [P, I32, I32, I32, I32, P, P]),
     "lt_spconv_fwd": (ctypes.c_int, [P, P, P, P, P, I64, I64, I32, I32, I32, P]),

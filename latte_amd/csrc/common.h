@@ -64,11 +64,14 @@ static inline int64_t lt_pow2_ge(int64_t x) {
 }
 
 // conv plan of a neighbour table [K,V] (built by lt_kmap_plan, consumed by lt_spconv_plan_fwd): one caller-owned buffer
-//   order [V] int32 | tnbr [T][K][64] int32 | tmask [T][K] uint64,   T = ceil(V/64), pieces 256-B aligned
+//   order [V] int32 | tnbr [T][K][64] int32 | tmask [T][K] uint64 | torder [T] int32,   T = ceil(V/64), 256-B aligned
+// torder = the tiles sorted by descending work (active strip-offsets): workgroups are dispatched heaviest first, which
+// removes the long tail a mask-sorted order otherwise has (the densest masks sort last).
 struct LtPlanView {
   int* order;
   int* tnbr;
   unsigned long long* tmask;
+  int* torder;
   int64_t bytes;
 };
 static inline LtPlanView lt_plan_view(void* mem, int K, int64_t V) {
@@ -82,6 +85,8 @@ static inline LtPlanView lt_plan_view(void* mem, int K, int64_t V) {
   off += lt_align_up((T > 0 ? T : 1) * K * 64 * 4, 256);
   v.tmask = (unsigned long long*)(p + off);
   off += lt_align_up((T > 0 ? T : 1) * K * 8, 256);
+  v.torder = (int*)(p + off);
+  off += lt_align_up((T > 0 ? T : 1) * 4, 256);
   v.bytes = off;
   return v;
 }

@@ -287,21 +287,41 @@ extern "C" int lt_kmap_order(const int32_t* table, int32_t K, int64_t V, void* w
 // one 256-thread block per 64-row tile: wave w handles offsets k = w, w+4, ...; lane i = row i of the tile
 __global__ __launch_bounds__(256) void k_plan_tiles(const int* __restrict__ table, int K, int64_t V,
                                                     const int* __restrict__ order, int* __restrict__ tnbr,
-                                                    unsigned long long* __restrict__ tmask) {
+                                                    unsigned long long* __restrict__ tmask,
+                                                    unsigned int* __restrict__ twork, int* __restrict__ tiota) {
+  __shared__ int s_work[4];
   const int64_t tile = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t slot = tile * 64 + lane;
   const int row = slot < V ? order[slot] : -1;
+  int work = 0;  // active (16-row strip, offset) pairs of the tile = MFMA work of its workgroup
   for (int k = wave; k < K; k += 4) {
     const int v = row >= 0 ? table[(int64_t)k * V + row] : -1;
     tnbr[(tile * K + k) * 64 + lane] = v;
     const unsigned long long m = __ballot(v >= 0);
     if (lane == 0) tmask[tile * K + k] = m;
+    for (int st = 0; st < 4; ++st) work += ((m >> (16 * st)) & 0xFFFFull) ? 1 : 0;
+  }
+  if (lane == 0) s_work[wave] = work;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    twork[tile] = (unsigned int)(s_work[0] + s_work[1] + s_work[2] + s_work[3]);
+    tiota[tile] = (int)tile;
   }
 }
 
 extern "C" int64_t lt_kmap_plan_bytes(int32_t K, int64_t V) { return lt_plan_view(nullptr, K, V).bytes; }
-extern "C" int64_t lt_kmap_plan_workspace_bytes(int64_t V) { return lt_kmap_order_workspace_bytes(V); }
+static int64_t tile_sort_bytes(int64_t t) {
+  size_t b = 0;
+  unsigned int* k = nullptr;
+  int* v = nullptr;
+  (void)rocprim::radix_sort_pairs_desc(nullptr, b, k, k, v, v, (size_t)(t > 0 ? t : 1), 0, 32, (hipStream_t)0);
+  return (int64_t)b;
+}
+extern "C" int64_t lt_kmap_plan_workspace_bytes(int64_t V) {
+  const int64_t T = (V + 63) / 64 > 0 ? (V + 63) / 64 : 1;
+  return lt_kmap_order_workspace_bytes(V) + 3 * lt_align_up(T * 4, 256) + lt_align_up(tile_sort_bytes(T), 256) + 1024;
+}
 
 extern "C" int lt_kmap_plan(const int32_t* table, int32_t K, int64_t V, void* ws, int64_t ws_bytes, void* plan,
                             int64_t plan_bytes, hipStream_t stream) {
@@ -312,10 +332,22 @@ extern "C" int lt_kmap_plan(const int32_t* table, int32_t K, int64_t V, void* ws
   LtPlanView pv = lt_plan_view(plan, K, V);
   LT_REQUIRE(plan_bytes >= pv.bytes, LT_ERR_WORKSPACE, "lt_kmap_plan: plan needs %lld bytes, got %lld",
              (long long)pv.bytes, (long long)plan_bytes);
-  int rc = lt_kmap_order(table, K, V, ws, ws_bytes, pv.order, stream);
+  LT_REQUIRE(ws_bytes >= lt_kmap_plan_workspace_bytes(V), LT_ERR_WORKSPACE, "lt_kmap_plan: workspace too small");
+  const int64_t ob = lt_kmap_order_workspace_bytes(V);
+  int rc = lt_kmap_order(table, K, V, ws, ob, pv.order, stream);
   if (rc) return rc;
   const int64_t T = (V + 63) / 64;
-  hipLaunchKernelGGL(k_plan_tiles, dim3((unsigned)T), dim3(256), 0, stream, table, K, V, pv.order, pv.tnbr, pv.tmask);
+  LtArena a((char*)ws + ob, ws_bytes - ob);
+  unsigned int* twork = (unsigned int*)a.take(T * 4);
+  unsigned int* twork_s = (unsigned int*)a.take(T * 4);
+  int* tiota = (int*)a.take(T * 4);
+  const int64_t sb = tile_sort_bytes(T);
+  void* tmp = a.take(sb);
+  LT_REQUIRE(twork && twork_s && tiota && tmp, LT_ERR_WORKSPACE, "lt_kmap_plan: arena exhausted");
+  hipLaunchKernelGGL(k_plan_tiles, dim3((unsigned)T), dim3(256), 0, stream, table, K, V, pv.order, pv.tnbr, pv.tmask,
+                     twork, tiota);
   LT_LAUNCH_CHECK();
+  size_t sbs = (size_t)sb;
+  LT_CHECK_HIP(rocprim::radix_sort_pairs_desc(tmp, sbs, twork, twork_s, tiota, pv.torder, (size_t)T, 0, 8, stream));
   return LT_OK;
 }

@@ -272,6 +272,7 @@ struct PlanArgs {
   const int* tnbr;                    // [T][K][64]
   const unsigned long long* tmask;    // [T][K]
   const int* order;                   // [Vout]
+  const int* torder;                  // [T] tiles by descending work
   float* out;
   int Vin, Vout, Cin, Cout, K;
 };
@@ -295,7 +296,8 @@ __global__ __launch_bounds__(256) void k_spconv_plan(PlanArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, q = lane >> 4;
-  const int64_t tile0 = (int64_t)blockIdx.x * SR;              // first plan tile of this workgroup
+  // first plan tile of this workgroup; single-tile workgroups are dispatched heaviest first
+  const int64_t tile0 = SR == 1 ? (int64_t)a.torder[blockIdx.x] : (int64_t)blockIdx.x * SR;
   const int64_t T = ((int64_t)a.Vout + LT_TM - 1) / LT_TM;
   const int J = a.Cin / 16, NTt = a.Cout / 16, nt0 = blockIdx.y * NT;
 
@@ -456,8 +458,177 @@ static int launch_plan(const PlanArgs& a, hipStream_t stream) {
   return LT_OK;
 }
 
-extern "C" int lt_spconv_plan_fwd(const float* in, const float* packed, const void* plan, float* out, int64_t Vin,
-                                  int64_t Vout, int32_t Cin, int32_t Cout, int32_t K, hipStream_t stream) {
+// =====================================================================================================
+// Register-fed planned kernel (no LDS operands, no barriers in the main loop).
+//
+// A workgroup owns SR 16-row strips (SR/4 plan tiles); its W waves own the SAME rows and different 16*NTW-column groups,
+// so every wave of a workgroup does the same amount of work for every (offset, strip) -- there is no intra-workgroup
+// imbalance to wait for, and a strip without a neighbour at offset k is skipped by all waves alike.
+// Operands go global/L2 -> VGPR directly: the packed weight fragment of (k, 16-channel group j, column tile) is one
+// coalesced 1-KiB load, the gathered A rows are 16 x 64-B pieces.  The next slab's operands are loaded into a second
+// register set while the current slab's MFMAs run; latency beyond that is covered by the other resident waves.
+// Summation order per output element is unchanged (k ascending, channel ascending) -> bitwise equal to the others.
+template <int SR, int NTW, int W>
+__global__ __launch_bounds__(64 * W) void k_spconv_rf(PlanArgs a) {
+  constexpr int TPW = SR / 4;          // plan tiles per workgroup
+  constexpr int TMW = 16 * SR;         // rows per workgroup
+  __shared__ int s_nbr[LT_KMAX * TMW]; // [nact][TMW] neighbour rows of the active offsets
+  __shared__ int s_rows[TMW];
+  __shared__ int s_klist[LT_KMAX];
+  __shared__ unsigned int s_act[LT_KMAX];  // per active offset: bit h = strip h has a neighbour
+  __shared__ int s_nact;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  const int64_t tile0 = TPW == 1 ? (int64_t)a.torder[blockIdx.x] : (int64_t)blockIdx.x * TPW;
+  const int64_t T = ((int64_t)a.Vout + LT_TM - 1) / LT_TM;
+  const int J = a.Cin / 16, NTt = a.Cout / 16;
+  const int nt0 = (blockIdx.y * W + wave) * NTW;
+
+  if (wave == 0) {
+    unsigned int act = 0u;
+#pragma unroll
+    for (int h = 0; h < TPW; ++h) {
+      unsigned long long m = 0ull;
+      if (lane < a.K && tile0 + h < T) m = a.tmask[(tile0 + h) * a.K + lane];
+#pragma unroll
+      for (int st = 0; st < 4; ++st)
+        if ((m >> (16 * st)) & 0xFFFFull) act |= 1u << (4 * h + st);
+    }
+    const unsigned long long bal = __ballot(act != 0u);
+    if (act != 0u) {
+      const int pos = __popcll(bal & ((1ull << lane) - 1ull));
+      s_klist[pos] = lane;
+      s_act[pos] = act;
+    }
+    if (lane == 0) s_nact = __popcll(bal);
+  }
+  for (int i = tid; i < TMW; i += 64 * W) {
+    const int64_t slot = tile0 * LT_TM + i;
+    s_rows[i] = slot < a.Vout ? a.order[slot] : -1;
+  }
+  __syncthreads();
+  const int nact = s_nact;
+  for (int e = tid; e < nact * TMW; e += 64 * W) {
+    const int ki = e / TMW, i = e - ki * TMW;
+    const int h = i >> 6;
+    int v = -1;
+    if (tile0 + h < T) v = a.tnbr[((tile0 + h) * a.K + s_klist[ki]) * LT_TM + (i & 63)];
+    if (v >= a.Vin) v = -1;  // defensive: never gather out of bounds
+    s_nbr[e] = v;
+  }
+  __syncthreads();
+
+  f32x4 acc[SR][NTW];
+#pragma unroll
+  for (int h = 0; h < SR; ++h)
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) acc[h][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int U = nact * J;  // slabs (ki, j), j fastest
+  const float* in_q = a.in + 4 * q;
+  const f32x4* wfrag = reinterpret_cast<const f32x4*>(a.packed) + (int64_t)nt0 * 64 + lane;
+
+  // Loads are unconditional (a missing neighbour or an inactive strip reads row 0, the value is dropped at compute
+  // time), so the main loop has no branch around a load and hipcc can keep the NEXT slab's loads in flight with a
+  // counted s_waitcnt while the current slab's MFMAs run.
+  auto issue = [&](int ki, int j, f32x4 (&av)[SR], f32x4 (&bv)[NTW], unsigned int& valid) {
+    const int k = __builtin_amdgcn_readfirstlane(s_klist[ki]);
+    const f32x4* wp = wfrag + ((int64_t)k * J + j) * NTt * 64;
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) bv[n] = wp[n * 64];
+    valid = 0u;
+#pragma unroll
+    for (int h = 0; h < SR; ++h) {
+      const int src = s_nbr[ki * TMW + 16 * h + r];
+      valid |= (src >= 0 ? 1u : 0u) << h;
+      av[h] = *reinterpret_cast<const f32x4*>(in_q + (int64_t)(src < 0 ? 0 : src) * a.Cin + 16 * j);
+    }
+  };
+  auto compute = [&](unsigned int act, const f32x4 (&av)[SR], const f32x4 (&bv)[NTW], unsigned int valid) {
+#pragma unroll
+    for (int h = 0; h < SR; ++h) {
+      if (act & (1u << h)) {  // wave-uniform: the strip has a neighbour at this offset
+        const bool ok = (valid >> h) & 1u;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float at = ok ? av[h][t] : 0.f;
+#pragma unroll
+          for (int n = 0; n < NTW; ++n)
+            acc[h][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(at, bv[n][t], acc[h][n], 0, 0, 0);
+        }
+      }
+    }
+  };
+  auto act_of = [&](int ki) -> unsigned int { return __builtin_amdgcn_readfirstlane(s_act[ki]); };
+
+  f32x4 avA[SR], avB[SR], bA[NTW], bB[NTW];
+  unsigned int vA = 0u, vB = 0u;
+  if (U > 0) {
+    // slab u = (ki, j); slabs past the end are clamped to the last one and computed with an empty strip mask
+    int ki = 0, jj = 0;
+    auto advance = [&]() {
+      if (ki * J + jj + 1 < U) {
+        if (++jj == J) { jj = 0; ++ki; }
+      }
+    };
+    issue(0, 0, avA, bA, vA);
+    for (int u = 0; u < U; u += 2) {
+      const unsigned int act0 = act_of(ki);
+      advance();
+      issue(ki, jj, avB, bB, vB);
+      compute(act0, avA, bA, vA);
+      const unsigned int act1 = (u + 1 < U) ? act_of(ki) : 0u;
+      advance();
+      issue(ki, jj, avA, bA, vA);
+      compute(act1, avB, bB, vB);
+    }
+  }
+
+#pragma unroll
+  for (int h = 0; h < SR; ++h) {
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int row = s_rows[16 * h + 4 * q + reg];
+      if (row >= 0) {
+        float* o = a.out + (int64_t)row * a.Cout + 16 * nt0 + r;
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) o[16 * n] = acc[h][n][reg];
+      }
+    }
+  }
+}
+
+template <int SR, int NTW, int W>
+static void launch_rf_one(const PlanArgs& a, int gy, hipStream_t stream) {
+  const int64_t rows = 16 * SR;
+  dim3 grid((unsigned)((a.Vout + rows - 1) / rows), (unsigned)gy);
+  hipLaunchKernelGGL((k_spconv_rf<SR, NTW, W>), grid, dim3(64 * W), 0, stream, a);
+}
+
+template <int NTW>
+static int launch_rf(const PlanArgs& a, int sr, hipStream_t stream) {
+  const int groups = a.Cout / (16 * NTW);  // column groups of one wave each
+  int w = 1;
+  for (int c = 4; c >= 1; --c)
+    if (groups % c == 0) { w = c; break; }
+  const int gy = groups / w;
+#define LT_RF(SRv, Wv) launch_rf_one<SRv, NTW, Wv>(a, gy, stream)
+  if (sr == 8) {
+    if (w == 4) LT_RF(8, 4); else if (w == 3) LT_RF(8, 3); else if (w == 2) LT_RF(8, 2); else LT_RF(8, 1);
+  } else {
+    if (w == 4) LT_RF(4, 4); else if (w == 3) LT_RF(4, 3); else if (w == 2) LT_RF(4, 2); else LT_RF(4, 1);
+  }
+#undef LT_RF
+  LT_LAUNCH_CHECK();
+  return LT_OK;
+}
+
+// variant: 0 = default choice, otherwise 100*SR + NTW (tuning / tests)
+extern "C" int lt_spconv_plan_fwd_v(const float* in, const float* packed, const void* plan, float* out, int64_t Vin,
+                                    int64_t Vout, int32_t Cin, int32_t Cout, int32_t K, int32_t variant,
+                                    hipStream_t stream) {
   LT_REQUIRE(Vin >= 0 && Vout >= 0 && Vin < INT32_MAX && Vout < INT32_MAX, LT_ERR_RANGE, "lt_spconv_plan_fwd: bad row counts");
   LT_REQUIRE(K >= 1 && K <= LT_KMAX, LT_ERR_ARG, "lt_spconv_plan_fwd: kernel volume %d not in [1,%d]", K, LT_KMAX);
   LT_REQUIRE(Cin >= 16 && Cin % 16 == 0, LT_ERR_ARG, "lt_spconv_plan_fwd: Cin=%d must be a multiple of 16", Cin);
@@ -466,14 +637,34 @@ extern "C" int lt_spconv_plan_fwd(const float* in, const float* packed, const vo
   LT_REQUIRE(packed && plan && out && (Vin == 0 || in), LT_ERR_ARG, "lt_spconv_plan_fwd: null pointer");
   LT_REQUIRE(((uintptr_t)plan & 15) == 0, LT_ERR_ARG, "lt_spconv_plan_fwd: plan must be 16-byte aligned");
   LtPlanView pv = lt_plan_view(const_cast<void*>(plan), K, Vout);
-  PlanArgs a{in, packed, pv.tnbr, pv.tmask, pv.order, out, (int)Vin, (int)Vout, Cin, Cout, K};
+  PlanArgs a{in, packed, pv.tnbr, pv.tmask, pv.order, pv.torder, out, (int)Vin, (int)Vout, Cin, Cout, K};
   const int ntt = Cout / 16;
-  if (ntt % 8 == 0) return launch_plan<8, 2>(a, stream);
-  if (ntt % 6 == 0) return launch_plan<6, 2>(a, stream);
-  if (ntt % 4 == 0) return launch_plan<4, 4>(a, stream);
-  if (ntt % 3 == 0) return launch_plan<3, 4>(a, stream);
-  if (ntt % 2 == 0) return launch_plan<2, 8>(a, stream);
-  return launch_plan<1, 8>(a, stream);
+  // default: 64-row workgroups, 2 column tiles per wave (measured best on every U-Net level); 1 tile per wave when
+  // that would leave fewer than 2 waves per SIMD on the chip (small levels)
+  const int64_t T = (Vout + LT_TM - 1) / LT_TM;
+  int sr = 4, ntw = (ntt % 2 == 0 && T * (ntt / 2) >= 2048) ? 2 : 1;
+  if (variant == 1) {  // the LDS-DMA staged kernel
+    if (ntt % 8 == 0) return launch_plan<8, 2>(a, stream);
+    if (ntt % 6 == 0) return launch_plan<6, 2>(a, stream);
+    if (ntt % 4 == 0) return launch_plan<4, 4>(a, stream);
+    if (ntt % 3 == 0) return launch_plan<3, 4>(a, stream);
+    if (ntt % 2 == 0) return launch_plan<2, 8>(a, stream);
+    return launch_plan<1, 8>(a, stream);
+  }
+  if (variant >= 100) {
+    sr = variant / 100;
+    ntw = variant % 100;
+    LT_REQUIRE((sr == 4 || sr == 8) && (ntw == 1 || ntw == 2 || ntw == 4) && ntt % ntw == 0, LT_ERR_ARG,
+               "lt_spconv_plan_fwd_v: bad variant %d for Cout=%d", variant, Cout);
+  }
+  if (ntw == 4) return launch_rf<4>(a, sr, stream);
+  if (ntw == 2) return launch_rf<2>(a, sr, stream);
+  return launch_rf<1>(a, sr, stream);
+}
+
+extern "C" int lt_spconv_plan_fwd(const float* in, const float* packed, const void* plan, float* out, int64_t Vin,
+                                  int64_t Vout, int32_t Cin, int32_t Cout, int32_t K, hipStream_t stream) {
+  return lt_spconv_plan_fwd_v(in, packed, plan, out, Vin, Vout, Cin, Cout, K, 0, stream);
 }
 
 template <int NT>

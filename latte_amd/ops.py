@@ -221,7 +221,11 @@ def spconv(feats: torch.Tensor, packed: torch.Tensor, nbr: torch.Tensor, cout: i
     return out
 
 
-def spconv_plan(feats: torch.Tensor, packed: torch.Tensor, plan: torch.Tensor, K: int, Vout: int, cout: int):
+CONV_VARIANT = 0  # lt_spconv_plan_fwd_v variant (0 = library default); tuning knob of tools/conv_bench.py
+
+
+def spconv_plan(feats: torch.Tensor, packed: torch.Tensor, plan: torch.Tensor, K: int, Vout: int, cout: int,
+                variant: int | None = None):
     """spconv through a plan of the [K,Vout] table (the hot path; Cin % 16 == 0)."""
     feats = _chk(feats, torch.float32, "spconv feats")
     packed = _chk(packed, torch.float32, "spconv packed")
@@ -232,7 +236,8 @@ def spconv_plan(feats: torch.Tensor, packed: torch.Tensor, plan: torch.Tensor, K
     if CONV_TRACE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.call("lt_spconv_plan_fwd", _p(feats), _p(packed), _p(plan), _p(out), Vin, Vout, Cin, int(cout), K, _stream())
+    _lib.call("lt_spconv_plan_fwd_v", _p(feats), _p(packed), _p(plan), _p(out), Vin, Vout, Cin, int(cout), K,
+              int(CONV_VARIANT if variant is None else variant), _stream())
     if CONV_TRACE is not None:
         e1.record()
         CONV_TRACE.append((e0, e1, Cin, int(cout), K, Vout))

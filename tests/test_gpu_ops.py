@@ -191,14 +191,19 @@ def test_spconv_plan_is_bitwise_equal_to_table_kernel(scans_small, cin, cout, ks
     feats = torch.randn(c.shape[0], cin, generator=g).cuda()
     pw = ops.pack_weights(w, 0)
     a = ops.spconv(feats, pw, resd, cout)
-    b = ops.spconv_plan(feats, pw, ops.kmap_plan(resd), K, resd.shape[1], cout)
-    assert torch.equal(a, b)
+    plan = ops.kmap_plan(resd)
+    variants = [0, 1] + [100 * sr + ntw for sr in (4, 8) for ntw in (1, 2, 4) if (cout // 16) % ntw == 0]
+    for v in variants:
+        b = ops.spconv_plan(feats, pw, plan, K, resd.shape[1], cout, variant=v)
+        assert torch.equal(a, b), v
     rev = ops.kmap_reverse(resd, c.shape[0])
     gout = torch.randn(out_coords.shape[0], cout, generator=g).cuda()
     pwt = ops.pack_weights(w, 1)
     a = ops.spconv(gout, pwt, rev, cin)
-    b = ops.spconv_plan(gout, pwt, ops.kmap_plan(rev), K, c.shape[0], cin)
-    assert torch.equal(a, b)
+    rplan = ops.kmap_plan(rev)
+    for v in [0, 1] + [100 * sr + ntw for sr in (4, 8) for ntw in (1, 2, 4) if (cin // 16) % ntw == 0]:
+        b = ops.spconv_plan(gout, pwt, rplan, K, c.shape[0], cin, variant=v)
+        assert torch.equal(a, b), v
 
 
 def test_spconv_plan_empty_rows_and_ragged_tail():
@@ -214,9 +219,11 @@ def test_spconv_plan_empty_rows_and_ragged_tail():
     pw = ops.pack_weights((torch.randn(K, C, C, generator=g) / 10).cuda(), 0)
     nd = nbr.cuda()
     a = ops.spconv(feats, pw, nd, C)
-    b = ops.spconv_plan(feats, pw, ops.kmap_plan(nd), K, V, C)
-    assert torch.equal(a, b)
-    assert float(b[5].abs().max()) == 0.0
+    plan = ops.kmap_plan(nd)
+    for v in (0, 1, 401, 402, 801, 802):
+        b = ops.spconv_plan(feats, pw, plan, K, V, C, variant=v)
+        assert torch.equal(a, b), v
+        assert float(b[5].abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("V,C", [(2, 32), (37, 32), (5000, 96), (20000, 256)])

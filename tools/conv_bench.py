@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--full360", action="store_true", default=True)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--variant", type=int, default=0, help="lt_spconv_plan_fwd_v variant (with --order plan)")
     args = ap.parse_args()
 
     import torch
@@ -38,6 +39,7 @@ def main():
     from latte_amd.tensor import PointTensor
 
     dev = torch.device("cuda", 0)
+    ops.CONV_VARIANT = args.variant
     coords = []
     for b in range(args.scans):
         p, i = synth.make_scan(args.points, b, beams=32, full_360=True)
@@ -116,7 +118,7 @@ def main():
         us = 1e3 * e0.elapsed_time(e1) / args.reps
         flops = 2.0 * M * C * C
         comp_bytes = 4.0 * (V * C * 2 + 27 * C * C) + 4.0 * 27 * V
-        rows.append(dict(C=C, V=V, M=M, pairs_per_voxel=round(M / V, 2), us=round(us, 1),
+        rows.append(dict(variant=args.variant, C=C, V=V, M=M, pairs_per_voxel=round(M / V, 2), us=round(us, 1),
                          tflops=round(flops / us / 1e6, 2), frac_f32_mfma=round(flops / us / 1e6 / 157.3, 4),
                          compulsory_GBs=round(comp_bytes / us / 1e3, 1), gathered_GBs=round(4.0 * M * C / us / 1e3, 1)))
         print(json.dumps(rows[-1]), flush=True)
