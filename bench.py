@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scans", type=int, default=3, help="scans in the CPU-oracle sample")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not time the conv launches with HIP events")
+    ap.add_argument("--dump-conv", default=None, help="write the per-launch conv table of one step (JSON) here")
     ap.add_argument("--fwd-only", action="store_true", help="time teacher forward only (BASELINE config 5 style)")
     return ap.parse_args()
 
@@ -155,12 +156,20 @@ def main():
                 flops_step += 2.0 * m * cin * cout
             for (e0, e1, *_r) in trace:
                 ms_total += e0.elapsed_time(e1)
+            if args.dump_conv:
+                table = []
+                for i, (m, (_e0, _e1, cin, cout, k, v)) in enumerate(zip(pairs, trace[:per_step])):
+                    us = 1e3 * sum(trace[i + st * per_step][0].elapsed_time(trace[i + st * per_step][1])
+                                   for st in range(args.steps)) / args.steps
+                    table.append(dict(i=i, Cin=cin, Cout=cout, K=k, Vout=v, M=m, us=round(us, 1),
+                                      tflops=round(2.0 * m * cin * cout / us / 1e6, 2)))
+                json.dump(table, open(args.dump_conv, "w"))
             launches = len(trace)
             flops_total = flops_step * args.steps
             achieved = flops_total / (ms_total * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                    "kernel": "k_spconv_vec/k_spconv_scalar (fp32 MFMA sparse conv, all launches of the timed region)",
+                    "kernel": "k_spconv_rf (+k_spconv_scalar for the 4-channel stem): fp32 MFMA sparse conv, all launches of the timed region",
                     "launches": launches, "avg_launch_us": round(1e3 * ms_total / launches, 2),
                     "flops_per_launch": round(flops_total / launches),
                     "share_of_step": round(ms_total * 1e-3 / dt, 4)}

@@ -120,7 +120,7 @@ int lt_spconv_fwd(const float* in, const float* packed, const int32_t* nbr, cons
 int lt_spconv_plan_fwd(const float* in, const float* packed, const void* plan, float* out, int64_t Vin, int64_t Vout,
                        int32_t Cin, int32_t Cout, int32_t K, lt_stream_t stream);
 /* the same with an explicit kernel variant (tuning and tests): 0 = default, 1 = LDS-DMA staged kernel,
- * 100*SR + NTW = register-fed kernel with SR (4|8) 16-row strips per workgroup and NTW (1|2|4) column tiles per wave */
+ * 100*SR + NTW = register-fed kernel with SR (1|2|4|8) 16-row strips per workgroup and NTW (1|2|4) column tiles per wave */
 int lt_spconv_plan_fwd_v(const float* in, const float* packed, const void* plan, float* out, int64_t Vin, int64_t Vout,
                          int32_t Cin, int32_t Cout, int32_t K, int32_t variant, lt_stream_t stream);
 /* ------------------------------------------------------------------ BatchNorm(batch stats)+ReLU+residual

@@ -11,6 +11,13 @@
 #define LT_ERR_WORKSPACE (-3)
 #define LT_ERR_RANGE (-4)
 
+// rocPRIM's radix sort falls back to a merge sort below 1M items: ~17 tiny launches per sort at the sizes of this path
+// (2e4..1e6 keys).  Onesweep needs one launch per 8-bit digit plus two, so it is forced above 4096 items.
+#ifdef __HIPCC__
+#include <rocprim/device/device_radix_sort.hpp>
+using LtSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 4096>;
+#endif
+
 // thread-local message returned by lt_last_error()
 void lt_set_error(const char* fmt, ...);
 

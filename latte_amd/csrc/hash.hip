@@ -168,7 +168,7 @@ static int64_t sort_temp_bytes(int64_t n) {
   size_t bytes = 0;
   uint64_t* k = nullptr;
   int* v = nullptr;
-  (void)rocprim::radix_sort_pairs(nullptr, bytes, k, k, v, v, (size_t)(n > 0 ? n : 1), 0, 64, (hipStream_t)0);
+  (void)rocprim::radix_sort_pairs<LtSortConfig>(nullptr, bytes, k, k, v, v, (size_t)(n > 0 ? n : 1), 0, 64, (hipStream_t)0);
   return (int64_t)bytes;
 }
 
@@ -217,7 +217,7 @@ extern "C" int lt_unique_sorted(const int64_t* keys, int64_t n, int32_t key_bits
   LT_REQUIRE(V >= 1 && V <= n, LT_ERR_RANGE, "lt_unique_sorted: impossible unique count %lld of %lld", (long long)V,
              (long long)n);
   size_t tbs = (size_t)tb;
-  LT_CHECK_HIP(rocprim::radix_sort_pairs(stmp, tbs, ck, sk, cv, sv, (size_t)V, 0, (unsigned)key_bits, stream));
+  LT_CHECK_HIP(rocprim::radix_sort_pairs<LtSortConfig>(stmp, tbs, ck, sk, cv, sv, (size_t)V, 0, (unsigned)key_bits, stream));
   if (out_keys) LT_CHECK_HIP(hipMemcpyAsync(out_keys, sk, V * 8, hipMemcpyDeviceToDevice, stream));
   if (out_first) {
     hipLaunchKernelGGL(k_widen_i32, dim3(lt_grid(V, 256)), dim3(256), 0, stream, sv, V, out_first);

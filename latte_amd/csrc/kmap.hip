@@ -254,7 +254,7 @@ static int64_t order_sort_bytes(int64_t n) {
   size_t b = 0;
   unsigned int* k = nullptr;
   int* v = nullptr;
-  (void)rocprim::radix_sort_pairs(nullptr, b, k, k, v, v, (size_t)(n > 0 ? n : 1), 0, 32, (hipStream_t)0);
+  (void)rocprim::radix_sort_pairs<LtSortConfig>(nullptr, b, k, k, v, v, (size_t)(n > 0 ? n : 1), 0, 32, (hipStream_t)0);
   return (int64_t)b;
 }
 
@@ -279,7 +279,7 @@ extern "C" int lt_kmap_order(const int32_t* table, int32_t K, int64_t V, void* w
   hipLaunchKernelGGL(k_row_masks, dim3(lt_grid(V, 256)), dim3(256), 0, stream, table, K, V, masks, iota);
   LT_LAUNCH_CHECK();
   size_t sbs = (size_t)sb;
-  LT_CHECK_HIP(rocprim::radix_sort_pairs(tmp, sbs, masks, smasks, iota, order, (size_t)V, 0, (unsigned)K, stream));
+  LT_CHECK_HIP(rocprim::radix_sort_pairs<LtSortConfig>(tmp, sbs, masks, smasks, iota, order, (size_t)V, 0, (unsigned)K, stream));
   return LT_OK;
 }
 
@@ -315,7 +315,7 @@ static int64_t tile_sort_bytes(int64_t t) {
   size_t b = 0;
   unsigned int* k = nullptr;
   int* v = nullptr;
-  (void)rocprim::radix_sort_pairs_desc(nullptr, b, k, k, v, v, (size_t)(t > 0 ? t : 1), 0, 32, (hipStream_t)0);
+  (void)rocprim::radix_sort_pairs_desc<LtSortConfig>(nullptr, b, k, k, v, v, (size_t)(t > 0 ? t : 1), 0, 32, (hipStream_t)0);
   return (int64_t)b;
 }
 extern "C" int64_t lt_kmap_plan_workspace_bytes(int64_t V) {
@@ -348,6 +348,6 @@ extern "C" int lt_kmap_plan(const int32_t* table, int32_t K, int64_t V, void* ws
                      twork, tiota);
   LT_LAUNCH_CHECK();
   size_t sbs = (size_t)sb;
-  LT_CHECK_HIP(rocprim::radix_sort_pairs_desc(tmp, sbs, twork, twork_s, tiota, pv.torder, (size_t)T, 0, 8, stream));
+  LT_CHECK_HIP(rocprim::radix_sort_pairs_desc<LtSortConfig>(tmp, sbs, twork, twork_s, tiota, pv.torder, (size_t)T, 0, 8, stream));
   return LT_OK;
 }

@@ -470,8 +470,9 @@ static int launch_plan(const PlanArgs& a, hipStream_t stream) {
 // Summation order per output element is unchanged (k ascending, channel ascending) -> bitwise equal to the others.
 template <int SR, int NTW, int W>
 __global__ __launch_bounds__(64 * W) void k_spconv_rf(PlanArgs a) {
-  constexpr int TPW = SR / 4;          // plan tiles per workgroup
-  constexpr int TMW = 16 * SR;         // rows per workgroup
+  constexpr int TPW = SR >= 4 ? SR / 4 : 1;    // plan tiles per workgroup
+  constexpr int PARTS = SR >= 4 ? 1 : 4 / SR;  // workgroups per plan tile (SR < 4: a workgroup owns SR of its 4 strips)
+  constexpr int TMW = 16 * SR;                 // rows per workgroup
   __shared__ int s_nbr[LT_KMAX * TMW]; // [nact][TMW] neighbour rows of the active offsets
   __shared__ int s_rows[TMW];
   __shared__ int s_klist[LT_KMAX];
@@ -481,7 +482,9 @@ __global__ __launch_bounds__(64 * W) void k_spconv_rf(PlanArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, q = lane >> 4;
-  const int64_t tile0 = TPW == 1 ? (int64_t)a.torder[blockIdx.x] : (int64_t)blockIdx.x * TPW;
+  // workgroups that own at most one plan tile are dispatched heaviest tile first
+  const int64_t tile0 = TPW == 1 ? (int64_t)a.torder[blockIdx.x / PARTS] : (int64_t)blockIdx.x * TPW;
+  const int s0 = PARTS == 1 ? 0 : (int)(blockIdx.x % PARTS) * SR;  // first strip inside the plan tile
   const int64_t T = ((int64_t)a.Vout + LT_TM - 1) / LT_TM;
   const int J = a.Cin / 16, NTt = a.Cout / 16;
   const int nt0 = (blockIdx.y * W + wave) * NTW;
@@ -493,8 +496,8 @@ __global__ __launch_bounds__(64 * W) void k_spconv_rf(PlanArgs a) {
       unsigned long long m = 0ull;
       if (lane < a.K && tile0 + h < T) m = a.tmask[(tile0 + h) * a.K + lane];
 #pragma unroll
-      for (int st = 0; st < 4; ++st)
-        if ((m >> (16 * st)) & 0xFFFFull) act |= 1u << (4 * h + st);
+      for (int st = 0; st < (SR >= 4 ? 4 : SR); ++st)
+        if ((m >> (16 * (s0 + st))) & 0xFFFFull) act |= 1u << (4 * h + st);
     }
     const unsigned long long bal = __ballot(act != 0u);
     if (act != 0u) {
@@ -505,7 +508,7 @@ __global__ __launch_bounds__(64 * W) void k_spconv_rf(PlanArgs a) {
     if (lane == 0) s_nact = __popcll(bal);
   }
   for (int i = tid; i < TMW; i += 64 * W) {
-    const int64_t slot = tile0 * LT_TM + i;
+    const int64_t slot = tile0 * LT_TM + 16 * s0 + i;
     s_rows[i] = slot < a.Vout ? a.order[slot] : -1;
   }
   __syncthreads();
@@ -514,7 +517,7 @@ __global__ __launch_bounds__(64 * W) void k_spconv_rf(PlanArgs a) {
     const int ki = e / TMW, i = e - ki * TMW;
     const int h = i >> 6;
     int v = -1;
-    if (tile0 + h < T) v = a.tnbr[((tile0 + h) * a.K + s_klist[ki]) * LT_TM + (i & 63)];
+    if (tile0 + h < T) v = a.tnbr[((tile0 + h) * a.K + s_klist[ki]) * LT_TM + 16 * s0 + (i & 63)];
     if (v >= a.Vin) v = -1;  // defensive: never gather out of bounds
     s_nbr[e] = v;
   }
@@ -602,9 +605,14 @@ __global__ __launch_bounds__(64 * W) void k_spconv_rf(PlanArgs a) {
 
 template <int SR, int NTW, int W>
 static void launch_rf_one(const PlanArgs& a, int gy, hipStream_t stream) {
-  const int64_t rows = 16 * SR;
-  dim3 grid((unsigned)((a.Vout + rows - 1) / rows), (unsigned)gy);
-  hipLaunchKernelGGL((k_spconv_rf<SR, NTW, W>), grid, dim3(64 * W), 0, stream, a);
+  unsigned gx;
+  if (SR >= 4) {
+    const int64_t rows = 16 * SR;
+    gx = (unsigned)((a.Vout + rows - 1) / rows);
+  } else {
+    gx = (unsigned)(((a.Vout + LT_TM - 1) / LT_TM) * (4 / SR));
+  }
+  hipLaunchKernelGGL((k_spconv_rf<SR, NTW, W>), dim3(gx, (unsigned)gy), dim3(64 * W), 0, stream, a);
 }
 
 template <int NTW>
@@ -614,12 +622,17 @@ static int launch_rf(const PlanArgs& a, int sr, hipStream_t stream) {
   for (int c = 4; c >= 1; --c)
     if (groups % c == 0) { w = c; break; }
   const int gy = groups / w;
-#define LT_RF(SRv, Wv) launch_rf_one<SRv, NTW, Wv>(a, gy, stream)
-  if (sr == 8) {
-    if (w == 4) LT_RF(8, 4); else if (w == 3) LT_RF(8, 3); else if (w == 2) LT_RF(8, 2); else LT_RF(8, 1);
-  } else {
-    if (w == 4) LT_RF(4, 4); else if (w == 3) LT_RF(4, 3); else if (w == 2) LT_RF(4, 2); else LT_RF(4, 1);
-  }
+#define LT_RF(SRv)                                                                  \
+  do {                                                                              \
+    if (w == 4) launch_rf_one<SRv, NTW, 4>(a, gy, stream);                          \
+    else if (w == 3) launch_rf_one<SRv, NTW, 3>(a, gy, stream);                     \
+    else if (w == 2) launch_rf_one<SRv, NTW, 2>(a, gy, stream);                     \
+    else launch_rf_one<SRv, NTW, 1>(a, gy, stream);                                 \
+  } while (0)
+  if (sr == 8) LT_RF(8);
+  else if (sr == 4) LT_RF(4);
+  else if (sr == 2) LT_RF(2);
+  else LT_RF(1);
 #undef LT_RF
   LT_LAUNCH_CHECK();
   return LT_OK;
@@ -639,10 +652,15 @@ extern "C" int lt_spconv_plan_fwd_v(const float* in, const float* packed, const 
   LtPlanView pv = lt_plan_view(const_cast<void*>(plan), K, Vout);
   PlanArgs a{in, packed, pv.tnbr, pv.tmask, pv.order, pv.torder, out, (int)Vin, (int)Vout, Cin, Cout, K};
   const int ntt = Cout / 16;
-  // default: 64-row workgroups, 2 column tiles per wave (measured best on every U-Net level); 1 tile per wave when
-  // that would leave fewer than 2 waves per SIMD on the chip (small levels)
-  const int64_t T = (Vout + LT_TM - 1) / LT_TM;
-  int sr = 4, ntw = (ntt % 2 == 0 && T * (ntt / 2) >= 2048) ? 2 : 1;
+  // default: 2 column tiles per wave; the tallest workgroup (64, 32 or 16 rows) that still puts >= 10 000 waves on the
+  // chip -- a wave's slab chain is sequential, so coarse levels need short chains more than weight reuse (measured on
+  // every level/width of the U-Net: tools/conv_bench.py)
+  int ntw = ntt % 2 == 0 ? 2 : 1;
+  int sr = 1;
+  for (int c = 4; c >= 1; c >>= 1) {
+    const int64_t waves = ((Vout + 16 * c - 1) / (16 * c)) * (ntt / ntw);
+    if (waves >= 10000) { sr = c; break; }
+  }
   if (variant == 1) {  // the LDS-DMA staged kernel
     if (ntt % 8 == 0) return launch_plan<8, 2>(a, stream);
     if (ntt % 6 == 0) return launch_plan<6, 2>(a, stream);
@@ -654,7 +672,7 @@ extern "C" int lt_spconv_plan_fwd_v(const float* in, const float* packed, const 
   if (variant >= 100) {
     sr = variant / 100;
     ntw = variant % 100;
-    LT_REQUIRE((sr == 4 || sr == 8) && (ntw == 1 || ntw == 2 || ntw == 4) && ntt % ntw == 0, LT_ERR_ARG,
+    LT_REQUIRE((sr == 1 || sr == 2 || sr == 4 || sr == 8) && (ntw == 1 || ntw == 2 || ntw == 4) && ntt % ntw == 0, LT_ERR_ARG,
                "lt_spconv_plan_fwd_v: bad variant %d for Cout=%d", variant, Cout);
   }
   if (ntw == 4) return launch_rf<4>(a, sr, stream);

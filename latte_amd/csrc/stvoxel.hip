@@ -163,7 +163,7 @@ static int64_t sortseg_sort_bytes(int64_t n) {
   size_t b = 0;
   int64_t* k = nullptr;
   int* v = nullptr;
-  (void)rocprim::radix_sort_pairs(nullptr, b, k, k, v, v, (size_t)(n > 0 ? n : 1), 0, 64, (hipStream_t)0);
+  (void)rocprim::radix_sort_pairs<LtSortConfig>(nullptr, b, k, k, v, v, (size_t)(n > 0 ? n : 1), 0, 64, (hipStream_t)0);
   return (int64_t)b;
 }
 static int64_t sortseg_scan_bytes(int64_t n) {
@@ -203,7 +203,7 @@ extern "C" int lt_sort_segments(const int64_t* keys, int64_t E, int32_t key_bits
   LT_LAUNCH_CHECK();
   size_t sbs = (size_t)sb, cbs = (size_t)cb;
   // LSD radix sort is stable: equal keys keep ascending element order => segment head = first occurrence
-  LT_CHECK_HIP(rocprim::radix_sort_pairs(stmp, sbs, keys, skeys, iota, sorted_elem, (size_t)E, 0, 63, stream));
+  LT_CHECK_HIP(rocprim::radix_sort_pairs<LtSortConfig>(stmp, sbs, keys, skeys, iota, sorted_elem, (size_t)E, 0, 63, stream));
   auto it = rocprim::make_transform_iterator(rocprim::counting_iterator<int>(0), HeadFlag{skeys});
   LT_CHECK_HIP(rocprim::inclusive_scan(ctmp, cbs, it, vid, (size_t)E, rocprim::plus<int>(), stream));
   hipLaunchKernelGGL(k_emit_segments, dim3(lt_grid(E, 256)), dim3(256), 0, stream, skeys, sorted_elem, vid, E, inverse,
@@ -419,7 +419,7 @@ __global__ void k_cq_mask(const float* __restrict__ ety, const int* __restrict__
 static int64_t cq_sort_bytes(int64_t n) {
   size_t b = 0;
   int64_t* k = nullptr;
-  (void)rocprim::radix_sort_keys(nullptr, b, k, k, (size_t)(n > 0 ? n : 1), 0, 48, (hipStream_t)0);
+  (void)rocprim::radix_sort_keys<LtSortConfig>(nullptr, b, k, k, (size_t)(n > 0 ? n : 1), 0, 48, (hipStream_t)0);
   return (int64_t)b;
 }
 
@@ -445,7 +445,7 @@ extern "C" int lt_class_quantile_mask(const float* ety, const int32_t* label, in
   hipLaunchKernelGGL(k_cq_keys, dim3(lt_grid(n, 256)), dim3(256), 0, stream, ety, label, n, keys);
   LT_LAUNCH_CHECK();
   size_t sbs = (size_t)sb;
-  LT_CHECK_HIP(rocprim::radix_sort_keys(tmp, sbs, keys, skeys, (size_t)n, 0, 48, stream));
+  LT_CHECK_HIP(rocprim::radix_sort_keys<LtSortConfig>(tmp, sbs, keys, skeys, (size_t)n, 0, 48, stream));
   hipLaunchKernelGGL(k_cq_thresh, dim3(lt_cdiv(num_classes, 64)), dim3(64), 0, stream, skeys, n, num_classes, q, thresh);
   LT_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_cq_mask, dim3(lt_grid(n, 256)), dim3(256), 0, stream, ety, label, n, thresh, mask);

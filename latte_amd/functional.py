@@ -120,12 +120,28 @@ def _run_conv(feats, packed, kmap: KernelMap, use_reverse: bool, cout: int):
     return ops.spconv(feats, packed, kmap.results, cout, order=kmap.order())
 
 
+def _packed(weight, mode: int, cache: dict | None):
+    """MFMA-fragment image of `weight`, re-packed only when the parameter changed (under TRAIN.UPDATE_PARAMS == "norm"
+    the conv kernels are frozen: latte/common/utils/ema_util.py:16-24)."""
+    w = weight if weight.dim() == 3 else weight.unsqueeze(0)
+    if cache is None:
+        return ops.pack_weights(w, mode)
+    tag = (weight._version, weight.data_ptr())
+    hit = cache.get(mode)
+    if hit is not None and hit[0] == tag:
+        return hit[1]
+    packed = ops.pack_weights(w, mode)
+    cache[mode] = (tag, packed)
+    return packed
+
+
 class _SparseConv(Function):
     @staticmethod
-    def forward(ctx, feats, weight, kmap: KernelMap, transposed: bool):
+    def forward(ctx, feats, weight, kmap: KernelMap, transposed: bool, wcache=None):
         w = weight if weight.dim() == 3 else weight.unsqueeze(0)
         cout = w.shape[2]
-        packed = ops.pack_weights(w, 0)
+        packed = _packed(weight, 0, wcache)
+        ctx.wcache = wcache
         out = _run_conv(feats, packed, kmap, transposed, cout)
         ctx.kmap, ctx.transposed = kmap, transposed
         ctx.save_for_backward(feats, weight)
@@ -141,11 +157,11 @@ class _SparseConv(Function):
         if ctx.needs_input_grad[0]:
             cin = w.shape[1]
             if kmap.submanifold and not transposed:
-                gfeats = _run_conv(gout, ops.pack_weights(w, 2), kmap, False, cin)
+                gfeats = _run_conv(gout, _packed(weight, 2, ctx.wcache), kmap, False, cin)
             elif not transposed:
-                gfeats = _run_conv(gout, ops.pack_weights(w, 1), kmap, True, cin)
+                gfeats = _run_conv(gout, _packed(weight, 1, ctx.wcache), kmap, True, cin)
             else:
-                gfeats = _run_conv(gout, ops.pack_weights(w, 1), kmap, False, cin)
+                gfeats = _run_conv(gout, _packed(weight, 1, ctx.wcache), kmap, False, cin)
         if ctx.needs_input_grad[1]:
             # dW is only reached when TRAIN.UPDATE_PARAMS == "all" (latte/common/utils/ema_util.py:44-71); the
             # shipped Latte configs train norm layers only.  Device-side torch ops over the pair list (not HIP yet).
@@ -161,11 +177,11 @@ class _SparseConv(Function):
                 i_in, i_out = (p[:, 1], p[:, 0]) if transposed else (p[:, 0], p[:, 1])
                 gw[k] = feats[i_in].t() @ gout[i_out]
             gweight = gw if weight.dim() == 3 else gw[0]
-        return gfeats, gweight, None, None
+        return gfeats, gweight, None, None, None
 
 
-def sparse_conv(feats, weight, kmap: KernelMap, transposed: bool = False):
-    return _SparseConv.apply(feats, weight, kmap, transposed)
+def sparse_conv(feats, weight, kmap: KernelMap, transposed: bool = False, wcache: dict | None = None):
+    return _SparseConv.apply(feats, weight, kmap, transposed, wcache)
 
 
 class _BatchNorm(Function):

@@ -12,17 +12,27 @@ from .tensor import PointTensor, SparseTensor
 __all__ = ["initial_voxelize", "point_to_voxel", "voxel_to_point"]
 
 
-def initial_voxelize(z: PointTensor, init_res: float, after_res: float) -> SparseTensor:
-    new_float_coord = torch.cat([(z.C[:, :3] * init_res) / after_res, z.C[:, -1].view(-1, 1)], 1)
-    floor_c = torch.floor(new_float_coord)
-    pc_hash = ops.sphash(floor_c.int().contiguous())
-    # torch.unique(pc_hash): voxels of x0 are ordered by ascending 60-bit hash
-    sparse_hash, _, idx_query = ops.unique_sorted(pc_hash, key_bits=60, want_first=False)
-    counts = ops.spcount(idx_query.int(), sparse_hash.numel())
-    inserted_coords = LF.spvoxelize(floor_c, idx_query, counts)
-    inserted_coords = torch.round(inserted_coords).int()
+def initial_voxelize(z: PointTensor, init_res: float, after_res: float, cache: dict | None = None) -> SparseTensor:
+    """`cache` (optional, owned by the input batch): everything here except the pooled features depends on the
+    coordinates only, so a second forward over the same batch (teacher, then student: latte/tta/tools/latte.py:159,176)
+    reuses the voxel set, the point->voxel map and -- through the shared cmaps/kmaps dicts -- every kernel map/plan."""
+    if cache is not None and "x0" in cache:
+        new_float_coord, idx_query, counts, inserted_coords, cmaps, kmaps = cache["x0"]
+    else:
+        new_float_coord = torch.cat([(z.C[:, :3] * init_res) / after_res, z.C[:, -1].view(-1, 1)], 1)
+        floor_c = torch.floor(new_float_coord)
+        pc_hash = ops.sphash(floor_c.int().contiguous())
+        # torch.unique(pc_hash): voxels of x0 are ordered by ascending 60-bit hash
+        sparse_hash, _, idx_query = ops.unique_sorted(pc_hash, key_bits=60, want_first=False)
+        counts = ops.spcount(idx_query.int(), sparse_hash.numel())
+        inserted_coords = LF.spvoxelize(floor_c, idx_query, counts)
+        inserted_coords = torch.round(inserted_coords).int()
+        cmaps, kmaps = {}, {}
+        if cache is not None:
+            cache["x0"] = (new_float_coord, idx_query, counts, inserted_coords, cmaps, kmaps)
     inserted_feat = LF.spvoxelize(z.F, idx_query, counts)
     new_tensor = SparseTensor(inserted_feat, inserted_coords, 1)
+    new_tensor.cmaps, new_tensor.kmaps = cmaps, kmaps
     new_tensor.cmaps.setdefault(new_tensor.stride, new_tensor.coords)
     z.additional_features["idx_query"][1] = idx_query
     z.additional_features["counts"][1] = counts

@@ -51,7 +51,8 @@ def build_kernel_map(input: SparseTensor, kernel_size, stride, dilation):
     return kmap, out_coords
 
 
-def conv3d(input: SparseTensor, weight, bias=None, kernel_size=3, stride=1, dilation=1, transposed=False):
+def conv3d(input: SparseTensor, weight, bias=None, kernel_size=3, stride=1, dilation=1, transposed=False,
+           wcache: dict | None = None):
     """Functional sparse conv with torchsparse v1.4.0 semantics (kernel-map caching, transposed conv re-using the
     map of the finer stride, output coords from cmaps)."""
     feats = input.feats
@@ -63,14 +64,14 @@ def conv3d(input: SparseTensor, weight, bias=None, kernel_size=3, stride=1, dila
         output = SparseTensor(out_feats, input.coords, input.stride)
     elif not transposed:
         kmap, out_coords = build_kernel_map(input, kernel_size, stride, dilation)
-        out_feats = LF.sparse_conv(feats, weight, kmap, False)
+        out_feats = LF.sparse_conv(feats, weight, kmap, False, wcache)
         if bias is not None:
             out_feats = out_feats + bias
         output = SparseTensor(out_feats, out_coords, tuple(input.stride[k] * stride[k] for k in range(3)))
     else:
         tensor_stride = tuple(input.stride[k] // stride[k] for k in range(3))
         kmap = input.kmaps[(tensor_stride, kernel_size, stride, dilation)]
-        out_feats = LF.sparse_conv(feats, weight, kmap, True)
+        out_feats = LF.sparse_conv(feats, weight, kmap, True, wcache)
         if bias is not None:
             out_feats = out_feats + bias
         output = SparseTensor(out_feats, input.cmaps[tensor_stride], tensor_stride)
@@ -96,6 +97,7 @@ class Conv3d(nn.Module):
             self.bias = nn.Parameter(torch.zeros(out_channels))
         else:
             self.register_parameter("bias", None)
+        self._packed_cache = {}  # mode -> ((param version, data_ptr), packed image); see functional._packed
         self.reset_parameters()
 
     def extra_repr(self):
@@ -113,7 +115,8 @@ class Conv3d(nn.Module):
             self.bias.data.uniform_(-std, std)
 
     def forward(self, input: SparseTensor) -> SparseTensor:
-        return conv3d(input, self.kernel, self.bias, self.kernel_size, self.stride, self.dilation, self.transposed)
+        return conv3d(input, self.kernel, self.bias, self.kernel_size, self.stride, self.dilation, self.transposed,
+                      wcache=self._packed_cache)
 
 
 def _wrap(input: SparseTensor, feats) -> SparseTensor:

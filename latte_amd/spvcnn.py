@@ -120,8 +120,18 @@ class SPVCNN(nn.Module):
         return up[1](cat([y, skip]))
 
     def forward(self, x: SparseTensor) -> torch.Tensor:
+        # index structures (voxel sets, point<->voxel maps, kernel maps, conv plans) depend on x.C only: they are built
+        # by the first forward over a batch and reused by later ones (teacher then student see the same `lidar`)
+        cache = getattr(x, "_lt_cache", None)
+        if cache is None or cache.get("coords_ptr") != (x.C.data_ptr(), tuple(x.C.shape)):
+            cache = {"coords_ptr": (x.C.data_ptr(), tuple(x.C.shape)), "point": None}
+            x._lt_cache = cache
         z = PointTensor(x.F, x.C.float())
-        x0 = self._stem(initial_voxelize(z, self.pres, self.vres))
+        if cache["point"] is None:
+            cache["point"] = (z.idx_query, z.weights, z.additional_features)
+        else:
+            z.idx_query, z.weights, z.additional_features = cache["point"]
+        x0 = self._stem(initial_voxelize(z, self.pres, self.vres, cache))
         z0 = voxel_to_point(x0, z, nearest=False)
 
         x1 = self.stage1(point_to_voxel(x0, z0))

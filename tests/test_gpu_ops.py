@@ -192,7 +192,7 @@ def test_spconv_plan_is_bitwise_equal_to_table_kernel(scans_small, cin, cout, ks
     pw = ops.pack_weights(w, 0)
     a = ops.spconv(feats, pw, resd, cout)
     plan = ops.kmap_plan(resd)
-    variants = [0, 1] + [100 * sr + ntw for sr in (4, 8) for ntw in (1, 2, 4) if (cout // 16) % ntw == 0]
+    variants = [0, 1] + [100 * sr + ntw for sr in (1, 2, 4, 8) for ntw in (1, 2, 4) if (cout // 16) % ntw == 0]
     for v in variants:
         b = ops.spconv_plan(feats, pw, plan, K, resd.shape[1], cout, variant=v)
         assert torch.equal(a, b), v
@@ -201,7 +201,7 @@ def test_spconv_plan_is_bitwise_equal_to_table_kernel(scans_small, cin, cout, ks
     pwt = ops.pack_weights(w, 1)
     a = ops.spconv(gout, pwt, rev, cin)
     rplan = ops.kmap_plan(rev)
-    for v in [0, 1] + [100 * sr + ntw for sr in (4, 8) for ntw in (1, 2, 4) if (cin // 16) % ntw == 0]:
+    for v in [0, 1] + [100 * sr + ntw for sr in (1, 2, 4, 8) for ntw in (1, 2, 4) if (cin // 16) % ntw == 0]:
         b = ops.spconv_plan(gout, pwt, rplan, K, c.shape[0], cin, variant=v)
         assert torch.equal(a, b), v
 
@@ -220,7 +220,7 @@ def test_spconv_plan_empty_rows_and_ragged_tail():
     nd = nbr.cuda()
     a = ops.spconv(feats, pw, nd, C)
     plan = ops.kmap_plan(nd)
-    for v in (0, 1, 401, 402, 801, 802):
+    for v in (0, 1, 101, 102, 201, 202, 401, 402, 801, 802):
         b = ops.spconv_plan(feats, pw, plan, K, V, C, variant=v)
         assert torch.equal(a, b), v
         assert float(b[5].abs().max()) == 0.0
