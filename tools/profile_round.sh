@@ -1,0 +1,32 @@
+#!/bin/bash
+# rocprofv3 evidence for the round: kernel-trace stats of the bench command, then two PMC passes (HBM read / write bytes).
+# usage (on the GPU box): bash tools/profile_round.sh r01
+set -e
+TAG=${1:-r01}
+R=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp
+mkdir -p $R/gpurun_out/prof_$TAG
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$TAG -o kt -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof_$TAG/kt.log 2>&1
+cp /tmp/kt_$TAG/kt_kernel_stats.csv $R/gpurun_out/prof_$TAG/${TAG}_kernel_stats.csv
+grep -v "^[WEI]2026" $R/gpurun_out/prof_$TAG/kt.log | tail -1 > $R/gpurun_out/prof_$TAG/${TAG}_bench_under_rocprof.json
+timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pf_$TAG -o pf -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events > $R/gpurun_out/prof_$TAG/pf.log 2>&1
+timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pw_$TAG -o pw -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events > $R/gpurun_out/prof_$TAG/pw.log 2>&1
+python - <<PY
+import csv, collections, json
+out = {}
+for tag, f in (("FETCH_SIZE", "/tmp/pf_$TAG/pf_counter_collection.csv"), ("WRITE_SIZE", "/tmp/pw_$TAG/pw_counter_collection.csv")):
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != tag:
+            continue
+        k = r["Kernel_Name"].split("(")[0]
+        agg[k][0] += 1
+        agg[k][1] += float(r["Counter_Value"])
+    out[tag] = {k: {"dispatches": v[0], "sum": v[1], "per_dispatch": v[1] / v[0]} for k, v in agg.items()}
+json.dump(out, open("$R/gpurun_out/prof_$TAG/${TAG}_pmc_hbm.json", "w"), indent=1)
+conv = [k for k in out["FETCH_SIZE"] if "spconv" in k]
+n = sum(out["FETCH_SIZE"][k]["dispatches"] for k in conv)
+f = sum(out["FETCH_SIZE"][k]["sum"] for k in conv)
+w = sum(out["WRITE_SIZE"].get(k, {"sum": 0})["sum"] for k in conv)
+print("conv dispatches", n, "FETCH_SIZE/dispatch", f / n, "WRITE_SIZE/dispatch", w / n)
+PY
