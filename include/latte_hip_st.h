@@ -66,4 +66,11 @@ int64_t lt_class_quantile_workspace_bytes(int64_t n);
 int lt_class_quantile_mask(const float* ety, const int32_t* label, int64_t n, int32_t num_classes, float q, void* ws,
                            int64_t ws_bytes, uint8_t* mask, lt_stream_t stream);
 
+/* refine_pseudo_labels (latte/data/utils/refine_pseudo_labels.py:10-30, called at latte/tta/tools/latte.py:238): per class c
+ * of label[0..n), thresh_c = min(torch.median(vals[label==c]), cap) (lower middle element); keep[j] = !(vals[j] <
+ * thresh_label[j]) -- the caller sets label to the ignore value where keep is 0.  vals must be >= 0.  Same workspace as
+ * lt_class_quantile_mask. */
+int lt_class_median_mask(const float* vals, const int32_t* label, int64_t n, int32_t num_classes, float cap, void* ws,
+                         int64_t ws_bytes, uint8_t* keep, lt_stream_t stream);
+
 #endif

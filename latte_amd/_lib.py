@@ -69,6 +69,7 @@ SIGNATURES = {
     "lt_st_join": (ctypes.c_int, [P, I64, P, I64, P, I64, P, P, PI64, P]),
     "lt_class_quantile_workspace_bytes": (I64, [I64]),
     "lt_class_quantile_mask": (ctypes.c_int, [P, P, I64, I32, F32, P, I64, P, P]),
+    "lt_class_median_mask": (ctypes.c_int, [P, P, I64, I32, F32, P, I64, P, P]),
 }
 
 _lib = None

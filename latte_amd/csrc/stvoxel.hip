@@ -389,7 +389,10 @@ __global__ void k_cq_keys(const float* __restrict__ ety, const int* __restrict__
 }
 
 // one thread per class: segment of the class in the sorted keys -> torch.quantile threshold (fp32 arithmetic)
-__global__ void k_cq_thresh(const int64_t* __restrict__ skeys, int64_t n, int num_classes, float q, float* __restrict__ thresh) {
+// mode 0: torch.quantile(q) with linear interpolation (refine_ety);  mode 1: torch.median (lower middle element) clamped
+// to at most q (refine_pseudo_labels: thresh = min(median, 0.9))
+__global__ void k_cq_thresh(const int64_t* __restrict__ skeys, int64_t n, int num_classes, float q, int mode,
+                            float* __restrict__ thresh) {
 #pragma clang fp contract(off)
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= num_classes) return;
@@ -400,7 +403,12 @@ __global__ void k_cq_thresh(const int64_t* __restrict__ skeys, int64_t n, int nu
   hi = n;
   while (lo < hi) { const int64_t m = (lo + hi) >> 1; if (skeys[m] < ke) lo = m + 1; else hi = m; }
   const int64_t cnt = lo - b;
-  if (cnt == 0) { thresh[c] = INFINITY; return; }
+  if (cnt == 0) { thresh[c] = mode == 0 ? INFINITY : -INFINITY; return; }
+  if (mode == 1) {
+    const float med = __uint_as_float((unsigned int)(skeys[b + (cnt - 1) / 2] & 0xFFFFFFFFll));
+    thresh[c] = med < q ? med : q;
+    return;
+  }
   const float rank = q * (float)(cnt - 1);
   const float fl = floorf(rank), ce = ceilf(rank);
   const float w = rank - fl;
@@ -411,9 +419,11 @@ __global__ void k_cq_thresh(const int64_t* __restrict__ skeys, int64_t n, int nu
 }
 
 __global__ void k_cq_mask(const float* __restrict__ ety, const int* __restrict__ label, int64_t n, const float* __restrict__ thresh,
-                          unsigned char* __restrict__ mask) {
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    mask[i] = (ety[i] > thresh[label[i]]) ? 0 : 1;
+                          int mode, unsigned char* __restrict__ mask) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float t = thresh[label[i]];
+    mask[i] = mode == 0 ? ((ety[i] > t) ? 0 : 1) : ((ety[i] < t) ? 0 : 1);
+  }
 }
 
 static int64_t cq_sort_bytes(int64_t n) {
@@ -428,8 +438,21 @@ extern "C" int64_t lt_class_quantile_workspace_bytes(int64_t n) {
   return 2 * lt_align_up(n * 8, 256) + lt_align_up(cq_sort_bytes(n), 256) + 65536 * 4 + 1024;
 }
 
+static int class_mask_impl(const float* ety, const int32_t* label, int64_t n, int32_t num_classes, float q, int mode,
+                           void* ws, int64_t ws_bytes, uint8_t* mask, hipStream_t stream);
+
 extern "C" int lt_class_quantile_mask(const float* ety, const int32_t* label, int64_t n, int32_t num_classes, float q,
                                       void* ws, int64_t ws_bytes, uint8_t* mask, hipStream_t stream) {
+  return class_mask_impl(ety, label, n, num_classes, q, 0, ws, ws_bytes, mask, stream);
+}
+
+extern "C" int lt_class_median_mask(const float* vals, const int32_t* label, int64_t n, int32_t num_classes, float cap,
+                                    void* ws, int64_t ws_bytes, uint8_t* keep, hipStream_t stream) {
+  return class_mask_impl(vals, label, n, num_classes, cap, 1, ws, ws_bytes, keep, stream);
+}
+
+static int class_mask_impl(const float* ety, const int32_t* label, int64_t n, int32_t num_classes, float q, int mode,
+                           void* ws, int64_t ws_bytes, uint8_t* mask, hipStream_t stream) {
   LT_REQUIRE(n >= 0 && num_classes >= 1 && num_classes <= 65535, LT_ERR_ARG, "lt_class_quantile_mask: bad sizes");
   LT_REQUIRE(q >= 0.f && q <= 1.f, LT_ERR_ARG, "lt_class_quantile_mask: q must be in [0,1]");
   if (n == 0) return LT_OK;
@@ -446,9 +469,10 @@ extern "C" int lt_class_quantile_mask(const float* ety, const int32_t* label, in
   LT_LAUNCH_CHECK();
   size_t sbs = (size_t)sb;
   LT_CHECK_HIP(rocprim::radix_sort_keys<LtSortConfig>(tmp, sbs, keys, skeys, (size_t)n, 0, 48, stream));
-  hipLaunchKernelGGL(k_cq_thresh, dim3(lt_cdiv(num_classes, 64)), dim3(64), 0, stream, skeys, n, num_classes, q, thresh);
+  hipLaunchKernelGGL(k_cq_thresh, dim3(lt_cdiv(num_classes, 64)), dim3(64), 0, stream, skeys, n, num_classes, q, mode,
+                     thresh);
   LT_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_cq_mask, dim3(lt_grid(n, 256)), dim3(256), 0, stream, ety, label, n, thresh, mask);
+  hipLaunchKernelGGL(k_cq_mask, dim3(lt_grid(n, 256)), dim3(256), 0, stream, ety, label, n, thresh, mode, mask);
   LT_LAUNCH_CHECK();
   return LT_OK;
 }

@@ -451,3 +451,16 @@ def class_quantile_mask(ety, label, num_classes: int, q: float):
     _lib.call("lt_class_quantile_mask", _p(ety), _p(label), n, int(num_classes), float(q), _p(ws), ws.numel(), _p(mask),
               _stream())
     return mask.bool()
+
+
+def class_median_mask(vals, label, num_classes: int, cap: float):
+    """keep[j] = !(vals[j] < min(median of vals over j's class, cap)) -- refine_pseudo_labels' filter."""
+    vals = _chk(vals, torch.float32, "class_median vals")
+    label = _chk(label, torch.int32, "class_median label")
+    n = vals.numel()
+    lib = _lib.load()
+    ws = _ws(lib.lt_class_quantile_workspace_bytes(n), vals.device)
+    keep = torch.empty(n, dtype=torch.uint8, device=vals.device)
+    _lib.call("lt_class_median_mask", _p(vals), _p(label), n, int(num_classes), float(cap), _p(ws), ws.numel(), _p(keep),
+              _stream())
+    return keep.bool()

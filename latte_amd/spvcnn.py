@@ -100,7 +100,7 @@ class SPVCNN(nn.Module):
                 nn.Sequential(ResidualBlock(co + sk, co, ks=3, stride=1, dilation=1),
                               ResidualBlock(co, co, ks=3, stride=1, dilation=1))]))
         self.point_transforms = nn.ModuleList([
-            nn.Sequential(nn.Linear(a, b), nn.BatchNorm1d(b), nn.ReLU(True))
+            nn.Sequential(nn.Linear(a, b), spnn.BatchNorm(b), nn.ReLU(True))  # BatchNorm1d subclass: same state_dict keys
             for a, b in [(cs[0], cs[4]), (cs[4], cs[6]), (cs[6], cs[8])]])
         self.weight_initialization()
         self.dropout = nn.Dropout(0.3, True)
@@ -114,6 +114,14 @@ class SPVCNN(nn.Module):
     def _stem(self, x):
         x = _conv_bn(self.stem, x, 0, relu=True)
         return _conv_bn(self.stem, x, 3, relu=True)
+
+    def _pt(self, i: int, f: torch.Tensor) -> torch.Tensor:
+        """point_transforms[i] = Linear -> BatchNorm1d -> ReLU (latte/models/spvcnn.py:95-111); the GEMM stays in
+        torch/hipBLASLt, BN(batch stats)+ReLU is the fused HIP kernel."""
+        seq = self.point_transforms[i]
+        if not f.is_cuda:
+            return seq(f)
+        return seq[1].bn_feats(seq[0](f), relu=True)
 
     def _up(self, up, y, skip):
         y = up[0](y)
@@ -139,21 +147,21 @@ class SPVCNN(nn.Module):
         x3 = self.stage3(x2)
         x4 = self.stage4(x3)
         z1 = voxel_to_point(x4, z0)
-        z1.F = z1.F + self.point_transforms[0](z0.F)
+        z1.F = z1.F + self._pt(0, z0.F)
 
         y1 = point_to_voxel(x4, z1)
         y1.F = self.dropout(y1.F)
         y1 = self._up(self.up1, y1, x3)
         y2 = self._up(self.up2, y1, x2)
         z2 = voxel_to_point(y2, z1)
-        z2.F = z2.F + self.point_transforms[1](z1.F)
+        z2.F = z2.F + self._pt(1, z1.F)
 
         y3 = point_to_voxel(y2, z2)
         y3.F = self.dropout(y3.F)
         y3 = self._up(self.up3, y3, x1)
         y4 = self._up(self.up4, y3, x0)
         z3 = voxel_to_point(y4, z2)
-        z3.F = z3.F + self.point_transforms[2](z2.F)
+        z3.F = z3.F + self._pt(2, z2.F)
         return z3.F
 
 

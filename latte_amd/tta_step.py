@@ -69,13 +69,15 @@ def update_ema_norm(ema_model: nn.Module, model: nn.Module, alpha: float = 0.99)
     return ema_model
 
 
-def refine_pseudo_labels(probs: torch.Tensor, pseudo_label: torch.Tensor, ignore_label: int = -100) -> torch.Tensor:
-    """latte/data/utils/refine_pseudo_labels.py:10-30: per class, labels below min(class median, 0.9) are ignored."""
-    for cls in pseudo_label.unique():
-        idx = torch.nonzero(pseudo_label == cls).squeeze(1)
-        thresh = probs[idx].median().clamp(max=0.9)
-        pseudo_label[idx[probs[idx] < thresh]] = ignore_label
-    return pseudo_label
+def refine_pseudo_labels(probs: torch.Tensor, pseudo_label: torch.Tensor, ignore_label: int = -100,
+                         num_classes: int | None = None) -> torch.Tensor:
+    """latte/data/utils/refine_pseudo_labels.py:10-30: per class, labels below min(class median, 0.9) are ignored.
+    One sort + one threshold kernel + one mask kernel (lt_class_median_mask) instead of a per-class Python loop."""
+    if num_classes is None:
+        num_classes = int(pseudo_label.max().item()) + 1
+    from . import ops
+    keep = ops.class_median_mask(probs.float().contiguous(), pseudo_label.to(torch.int32).contiguous(), num_classes, 0.9)
+    return torch.where(keep, pseudo_label, torch.full_like(pseudo_label, ignore_label))
 
 
 def pc2img_logit(pc_logits: torch.Tensor, pc2img_idx_ls: List[torch.Tensor]):
@@ -163,7 +165,7 @@ class LatteStep:
             ps_prob = all_probs_3d
             ps_prob[pc2img_mask] = w2.unsqueeze(1) * probs_2d + w3.unsqueeze(1) * probs_3d
             ps_conf, ps_label = ps_prob.max(1)
-            ps_label = refine_pseudo_labels(ps_conf, ps_label)
+            ps_label = refine_pseudo_labels(ps_conf, ps_label, num_classes=self.num_classes)
 
         self._tick("pseudo_labels")
         loss_2d, loss_3d = [], []

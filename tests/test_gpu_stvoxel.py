@@ -64,6 +64,18 @@ def test_softmax_entropy_and_refine_known_answers():
     assert torch.allclose(ety.cpu(), hr_ref.prob_2_entropy(want_p).sum(1), rtol=1e-4, atol=1e-6)
     m = refine_ety(torch.from_numpy(z["refine_ety_in_ety"]).cuda(), torch.from_numpy(z["refine_ety_in_label"]).cuda(), 0.75)
     assert np.array_equal(m.cpu().numpy(), z["refine_ety_mask"])
+    # refine_pseudo_labels: golden vector captured from the reference's refine_pseudo_labels.py:10-30
+    from latte_amd.tta_step import refine_pseudo_labels
+    r = refine_pseudo_labels(torch.from_numpy(z["rpl_in_prob"]).cuda(), torch.from_numpy(z["rpl_in_label"]).cuda())
+    assert np.array_equal(r.cpu().numpy(), z["rpl_out"])
+    # larger random case against the oracle, incl. an empty class and even/odd class sizes (lower median)
+    g = torch.Generator().manual_seed(4)
+    prob = torch.rand(20001, generator=g)
+    lab = torch.randint(0, 7, (20001,), generator=g)
+    lab[lab == 3] = 5
+    want = hr_ref.refine_pseudo_labels(prob, lab)
+    got = refine_pseudo_labels(prob.cuda(), lab.cuda(), num_classes=9)
+    assert torch.equal(got.cpu(), want)
 
 
 @pytest.mark.parametrize("reduce", ["mean", "sum", "max"])
