@@ -19,7 +19,8 @@ __all__ = [
 
 
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # raw handle of torch's current stream on the current device (torch.cuda.current_stream() costs ~9 us per call)
+    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
 
 
 def _chk(t: torch.Tensor, dtype, name: str) -> torch.Tensor:

@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""cProfile of the host side of one TTA step (diagnostic)."""
+import cProfile, os, pstats, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from latte_amd import synth
+from latte_amd.spvcnn import Net3DSeg
+from latte_amd.tta_step import LatteStep
+from latte_amd.workload import build_batch, hr_cfg_of
+w = synth.workload("nuscenes_34k_w5")
+torch.manual_seed(1)
+model = Net3DSeg(w["C"], True, "SPVCNN", {"cr": 1.0}).cuda()
+step = LatteStep(model, w["C"], hr_cfg_of(w))
+batch = build_batch(w, device="cuda")
+for _ in range(3):
+    step.step(batch)
+torch.cuda.synchronize()
+pr = cProfile.Profile()
+pr.enable()
+for _ in range(5):
+    step.step(batch)
+torch.cuda.synchronize()
+pr.disable()
+st = pstats.Stats(pr)
+st.sort_stats("cumulative").print_stats(70)
+st.sort_stats("tottime").print_stats(40)
