@@ -88,7 +88,7 @@ def main():
     import torch.distributed as dist
     from latte_amd import _lib, ops, synth
     from latte_amd.spvcnn import Net3DSeg
-    from latte_amd.tta_step import LatteStep
+    from latte_amd.tta_step import LatteStep, shard_scan_offset
     from latte_amd.workload import build_batch, hr_cfg_of
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -108,7 +108,7 @@ def main():
     torch.manual_seed(1)  # cfg.RNG_SEED (latte/common/config/base.py:173); same weights on every rank
     model = Net3DSeg(w["C"], True, "SPVCNN", {"cr": args.cr}).to(dev)
     step = LatteStep(model, w["C"], hr_cfg_of(w), process_group=pg)
-    batch = build_batch(w, device=dev, scan_offset=rank * w["B"], seed=rank)
+    batch = build_batch(w, device=dev, scan_offset=shard_scan_offset(rank, w["B"]), seed=rank)
     n_points = batch["n_points"]
 
     def one_step():

@@ -87,6 +87,28 @@ def pc2img_logit(pc_logits: torch.Tensor, pc2img_idx_ls: List[torch.Tensor]):
     return mask, pc_logits[mask]
 
 
+def allreduce_mean_grads(params: List[torch.Tensor], world: int, group=None) -> None:
+    """The only collective of the path: ONE flat all-reduce (RCCL over xGMI on GPUs, gloo in the CPU tests) of the
+    gradients of `params` (the norm parameters: 13 248 floats at cr=1), averaged over the ranks, written back as views
+    of the flat buffer.  Parameters without a gradient contribute zeros."""
+    if world == 1:
+        return
+    grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in params]
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    torch.distributed.all_reduce(flat, group=group)
+    flat.div_(world)
+    off = 0
+    for p, g in zip(params, grads):
+        n = g.numel()
+        p.grad = flat[off:off + n].view_as(p)
+        off += n
+
+
+def shard_scan_offset(rank: int, scans_per_rank: int) -> int:
+    """first global scan id of a rank: ranks own whole, disjoint sequences (no halo, no data-path collective)"""
+    return rank * scans_per_rank
+
+
 class LatteStep:
     def __init__(self, model_3d: nn.Module, num_classes: int, hr_cfg: Dict, lr: float = 1e-3, conf_perc=None,
                  lambda_hr_23: float = 0.3, lambda_hr_32: float = 0.3, lambda_ety_ps: float = 1.0, class_weights=None,
@@ -185,18 +207,7 @@ class LatteStep:
         return {"hr_23": l23.detach(), "hr_32": l32.detach(), "pl_2d": pl2.detach(), "pl_3d": pl3.detach()}
 
     def allreduce_grads(self):
-        """The only collective of the path: ONE flat RCCL all-reduce of the norm gradients (13 248 floats at cr=1)."""
-        if self.world == 1:
-            return
-        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
-        flat = torch.cat([g.reshape(-1) for g in grads])
-        torch.distributed.all_reduce(flat, group=self.pg)
-        flat.div_(self.world)
-        off = 0
-        for p, g in zip(self.params, grads):
-            n = g.numel()
-            p.grad = flat[off:off + n].view_as(p)
-            off += n
+        allreduce_mean_grads(self.params, self.world, self.pg)
 
     def step(self, batch: Dict):
         # one TTA iteration = one new batch: index structures are built once per iteration (by the teacher forward) and

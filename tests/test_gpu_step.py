@@ -1,0 +1,75 @@
+"""One whole TTA iteration (teacher fwd, student fwd, 2x HR, pseudo labels, 2x CR, CE, backward) on the HIP path against
+the CPU oracle of the same iteration (oracle/step_ref.py), same weights, same synthetic batch.  Tolerance: 1e-3 relative
+on the losses (north_star), looser on whole-network gradients for the reason documented in test_gpu_spvcnn.py."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(name="tiny", cr=0.5):
+    from latte_amd import synth
+    from latte_amd.spvcnn import Net3DSeg
+    from latte_amd.tta_step import LatteStep
+    from latte_amd.workload import build_batch, hr_cfg_of
+    w = synth.workload(name)
+    torch.manual_seed(1)
+    model = Net3DSeg(w["C"], True, "SPVCNN", {"cr": cr})
+    g = torch.Generator().manual_seed(2)
+    for mod in model.modules():
+        if isinstance(mod, torch.nn.BatchNorm1d):
+            mod.weight.data = 0.5 + torch.rand(mod.weight.shape, generator=g)
+            mod.bias.data = 0.2 * torch.randn(mod.bias.shape, generator=g)
+    model = model.cuda()
+    step = LatteStep(model, w["C"], hr_cfg_of(w))
+    batch = build_batch(w, device="cuda")
+    return w, step, batch
+
+
+def test_tta_iteration_matches_oracle():
+    from latte_amd.workload import hr_cfg_of
+    from oracle import step_ref
+    w, step, batch = _setup()
+    sd_s = {k: v.detach().cpu() for k, v in step.model.state_dict().items()}
+    sd_t = {k: v.detach().cpu() for k, v in step.ema_model.state_dict().items()}
+    names = [f"{mn}.{pn}"[len("net_3d."):] for mn, mod in step.model.named_modules()
+             if isinstance(mod, torch.nn.BatchNorm1d) and mn.startswith("net_3d.") for pn, _ in mod.named_parameters()]
+    got = step.forward_backward(batch)
+    got = {k: float(v) for k, v in got.items()}
+    lidar = batch["lidar"]
+    want, grads, g2d, aux = step_ref.tta_step_ref(
+        sd_s, sd_t, lidar.C.cpu().numpy(), lidar.F.cpu(), [i.cpu().numpy() for i in batch["inverse_map"]],
+        [int(i.shape[0]) for i in batch["indices"]], [p.cpu() for p in batch["ori_points"]],
+        [m.cpu() for m in batch["pc2img_idx"]], [p.numpy() for p in batch["pose"]], batch["scene_name"], batch["scan_ID"],
+        batch["logit_2d_student"].detach().cpu(), batch["logit_2d_teacher"].cpu(), hr_cfg_of(w), grad_names=names)
+    for k in ("hr_23", "hr_32"):
+        assert abs(got[k] - want[k]) < 1e-3 * abs(want[k]), (k, got[k], want[k])
+    for k in ("pl_2d", "pl_3d"):  # discrete pseudo labels: a single flipped label moves the loss by ~1/N
+        assert abs(got[k] - want[k]) < 2e-3 * abs(want[k]), (k, got[k], want[k])
+    g = batch["logit_2d_student"].grad.cpu()
+    assert float((g - g2d).norm() / g2d.norm()) < 2e-3
+    params = dict(step.model.named_parameters())
+    errs = sorted(float((params["net_3d." + n].grad.cpu().double() - grads[n].double()).norm() /
+                        (grads[n].double().norm() + 1e-12)) for n in names)
+    assert errs[len(errs) // 2] < 1e-2, errs[len(errs) // 2]
+
+
+def test_step_updates_norm_parameters_only_and_ema_follows():
+    w, step, batch = _setup()
+    before = {k: v.detach().clone() for k, v in step.model.state_dict().items()}
+    ema_before = {k: v.detach().clone() for k, v in step.ema_model.state_dict().items()}
+    losses = step.step(batch)
+    assert all(np.isfinite(float(v)) for v in losses.values())
+    changed = {k for k, v in step.model.state_dict().items() if not torch.equal(v, before[k])}
+    norm_keys = {f"{mn}.{pn}" for mn, mod in step.model.named_modules() if "norm" in type(mod).__name__.lower()
+                 for pn, _ in mod.named_parameters()}
+    assert changed and changed <= norm_keys          # latte/common/utils/ema_util.py:16-24
+    for k in norm_keys:                                # update_ema_norm, alpha = 0.99 (ema_util.py:99-118)
+        want = 0.99 * ema_before[k] + 0.01 * step.model.state_dict()[k]
+        assert torch.allclose(step.ema_model.state_dict()[k], want, rtol=1e-6, atol=1e-7)
+    # index structures are rebuilt per iteration, shared inside one (teacher builds, student reuses)
+    cache = batch["lidar"]._lt_cache
+    assert cache is not None and "x0" in cache
+    step.step(batch)
+    assert batch["lidar"]._lt_cache is not cache
