@@ -12,7 +12,7 @@ collective).  Inputs are resident in HBM before the timed region.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline      the dominant kernel family (sparse-conv fp32 MFMA kernel): algorithmic flops / HIP-event time of its
-                launches inside the timed region
+                launches inside the timed region (the library's conv launch timer, lt_conv_timer_begin/end)
   cpu_baseline  the CPU oracle (oracle/step_ref.py, a port: the reference's torchsparse backend is not installable)
                 timed on this box's host cores on a bounded sample of the same workload
 """
@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scans", type=int, default=3, help="scans in the CPU-oracle sample")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not time the conv launches with HIP events")
+    ap.add_argument("--overlap", action="store_true", help="teacher and student forward on two HIP streams (no measured "
+                    "gain: the step is host-bound; per-kernel event times then include the other stream's kernels)")
     ap.add_argument("--dump-conv", default=None, help="write the per-launch conv table of one step (JSON) here")
     ap.add_argument("--fwd-only", action="store_true", help="time teacher forward only (BASELINE config 5 style)")
     return ap.parse_args()
@@ -107,7 +109,7 @@ def main():
     w = synth.workload(args.workload)
     torch.manual_seed(1)  # cfg.RNG_SEED (latte/common/config/base.py:173); same weights on every rank
     model = Net3DSeg(w["C"], True, "SPVCNN", {"cr": args.cr}).to(dev)
-    step = LatteStep(model, w["C"], hr_cfg_of(w), process_group=pg)
+    step = LatteStep(model, w["C"], hr_cfg_of(w), process_group=pg, overlap=args.overlap)
     batch = build_batch(w, device=dev, scan_offset=shard_scan_offset(rank, w["B"]), seed=rank)
     n_points = batch["n_points"]
 
@@ -119,11 +121,12 @@ def main():
 
     for _ in range(args.warmup):
         one_step()
-    trace = None if args.no_kernel_events else []
+    timed_kernels = not args.no_kernel_events
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    ops.CONV_TRACE = trace
+    if timed_kernels:
+        ops.conv_timer_begin(1 << 16)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
@@ -131,13 +134,13 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    ops.CONV_TRACE = None
+    trace = ops.conv_timer_end() if timed_kernels else None
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     pairs = None
-    if trace:
+    if timed_kernels:
         # pair counts M of every conv launch of a step, from one more (untimed) step on every rank: the launch sequence
         # and the kernel maps are the same in every step (same scans), only the BN parameters move
         ops.CONV_PAIRS = []
@@ -148,23 +151,19 @@ def main():
 
     if rank == 0:
         roof = None
-        if trace:
-            per_step = len(trace) // args.steps
-            assert len(pairs) == per_step, (len(pairs), per_step)
-            flops_step, ms_total = 0.0, 0.0
-            for m, (_e0, _e1, cin, cout, _k, _v) in zip(pairs, trace[:per_step]):
-                flops_step += 2.0 * m * cin * cout
-            for (e0, e1, *_r) in trace:
-                ms_total += e0.elapsed_time(e1)
+        if timed_kernels:
+            ms, meta = trace
+            per_step = len(ms) // args.steps
+            assert len(pairs) == per_step and per_step * args.steps == len(ms), (len(pairs), per_step, len(ms))
+            flops_step = sum(2.0 * m * int(cin) * int(cout) for m, (cin, cout, _k, _v) in zip(pairs, meta[:per_step]))
+            ms_total = float(ms.astype("float64").sum())
             if args.dump_conv:
-                table = []
-                for i, (m, (_e0, _e1, cin, cout, k, v)) in enumerate(zip(pairs, trace[:per_step])):
-                    us = 1e3 * sum(trace[i + st * per_step][0].elapsed_time(trace[i + st * per_step][1])
-                                   for st in range(args.steps)) / args.steps
-                    table.append(dict(i=i, Cin=cin, Cout=cout, K=k, Vout=v, M=m, us=round(us, 1),
-                                      tflops=round(2.0 * m * cin * cout / us / 1e6, 2)))
+                us = 1e3 * ms.reshape(args.steps, per_step).mean(0)
+                table = [dict(i=i, Cin=int(c[0]), Cout=int(c[1]), K=int(c[2]), Vout=int(c[3]), M=m, us=round(float(u), 1),
+                              tflops=round(2.0 * m * int(c[0]) * int(c[1]) / float(u) / 1e6, 2))
+                         for i, (m, c, u) in enumerate(zip(pairs, meta[:per_step], us))]
                 json.dump(table, open(args.dump_conv, "w"))
-            launches = len(trace)
+            launches = len(ms)
             flops_total = flops_step * args.steps
             achieved = flops_total / (ms_total * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -174,7 +173,7 @@ def main():
                     "flops_per_launch": round(flops_total / launches),
                     "share_of_step": round(ms_total * 1e-3 / dt, 4)}
             pmc = os.path.join(ROOT, "profiles", "conv_traffic.json")
-            if os.path.exists(pmc):
+            if os.path.exists(pmc) and args.workload == "nuscenes_34k_w5" and args.cr == 1.0 and not args.fwd_only:
                 try:
                     roof["traffic"] = json.load(open(pmc)).get("hbm_bytes_per_launch")
                 except Exception:

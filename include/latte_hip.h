@@ -123,12 +123,29 @@ int lt_spconv_plan_fwd(const float* in, const float* packed, const void* plan, f
  * 100*SR + NTW = register-fed kernel with SR (1|2|4|8) 16-row strips per workgroup and NTW (1|2|4) column tiles per wave */
 int lt_spconv_plan_fwd_v(const float* in, const float* packed, const void* plan, float* out, int64_t Vin, int64_t Vout,
                          int32_t Cin, int32_t Cout, int32_t K, int32_t variant, lt_stream_t stream);
+/* lt_spconv_plan_fwd that also writes, per workgroup b of the launch, the column sums of its output rows:
+ * partial[(b*2+0)*Cout + c] = sum out[:,c], partial[(b*2+1)*Cout + c] = sum out[:,c]^2, b < lt_spconv_stat_blocks(Vout,Cout)
+ * -- the BatchNorm statistics of the following spnn.BatchNorm (basic_blocks.py:22,40,56) without re-reading the output. */
+int64_t lt_spconv_stat_blocks(int64_t Vout, int32_t Cout);
+int lt_spconv_plan_fwd_stats(const float* in, const float* packed, const void* plan, float* out, int64_t Vin, int64_t Vout,
+                             int32_t Cin, int32_t Cout, int32_t K, float* partial, lt_stream_t stream);
+
+/* Conv launch timer -- measurement aid, no counterpart in the reference (bench.py's roofline leg uses it).  Between
+ * begin and end every sparse-conv kernel launch of this library (lt_spconv_fwd, lt_spconv_plan_fwd*, and the ones inside
+ * lt_conv_bn_fwd/bwd) is bracketed by two hipEvents on the launch stream.  lt_conv_timer_end [sync] waits for them and
+ * returns the number of launches n (<= capacity), ms[i] = duration, meta[4*i..] = Cin, Cout, K, Vout of launch i. */
+int lt_conv_timer_begin(int32_t capacity);
+int64_t lt_conv_timer_end(float* ms, int32_t* meta, int64_t capacity);
+
 /* ------------------------------------------------------------------ BatchNorm(batch stats)+ReLU+residual
  * spnn.BatchNorm + spnn.ReLU + skip add (basic_blocks.py:22-23,56-57,64,69,72,75); TTA forces batch
  * statistics (latte/common/utils/ema_util.py:26-29).  var is the biased variance. */
 int64_t lt_bn_workspace_bytes(int64_t V, int32_t C);
 int lt_bn_stats(const float* x, int64_t V, int32_t C, void* ws, int64_t ws_bytes, float* mean, float* var,
                 lt_stream_t stream);
+/* mean / biased variance from the column sums of lt_spconv_plan_fwd_stats (nb = lt_spconv_stat_blocks) */
+int lt_bn_finalize_sums(const float* partial, int64_t nb, int64_t V, int32_t C, float* mean, float* var,
+                        lt_stream_t stream);
 int lt_bn_apply(const float* x, const float* mean, const float* var, const float* gamma, const float* beta,
                 float eps, const float* residual, int32_t relu, float* y, int64_t V, int32_t C,
                 lt_stream_t stream);
@@ -140,6 +157,22 @@ int lt_bn_bwd_reduce(const float* dy, const float* x, const float* y, const floa
 int lt_bn_bwd_apply(const float* dy, const float* x, const float* y, const float* mean, const float* var,
                     const float* gamma, float eps, int32_t relu, const float* sum_g, const float* sum_gx,
                     float* dx, float* dres, int64_t V, int32_t C, lt_stream_t stream);
+
+/* ------------------------------------------------------------------ conv -> BN [+ residual] [+ ReLU] in one call
+ * The block pattern of latte/models/basic_blocks.py:13-76 (Conv3d, BatchNorm, ReLU / residual add) as ONE host call:
+ * conv with statistics epilogue -> finalize -> apply.  conv_out [Vout,Cout] is kept (the backward needs it), y is the
+ * block output.  Backward: BN backward (dgamma, dbeta, optional dres = gradient of the residual input), then the
+ * gradient w.r.t. the conv input through packed_bwd (mode 1 or 2) and the plan of the backward table; din may be NULL
+ * (then packed_bwd / plan_bwd are not needed), dconv is a [Vout,Cout] scratch/output buffer. */
+int64_t lt_conv_bn_workspace_bytes(int64_t Vout, int32_t Cout);
+int lt_conv_bn_fwd(const float* in, const float* packed, const void* plan, int64_t Vin, int64_t Vout, int32_t Cin,
+                   int32_t Cout, int32_t K, const float* gamma, const float* beta, float eps, const float* residual,
+                   int32_t relu, void* ws, int64_t ws_bytes, float* conv_out, float* y, float* mean, float* var,
+                   lt_stream_t stream);
+int lt_conv_bn_bwd(const float* dy, const float* conv_out, const float* y, const float* mean, const float* var,
+                   const float* gamma, float eps, int32_t relu, int64_t Vout, int32_t Cout, void* ws, int64_t ws_bytes,
+                   float* dgamma, float* dbeta, float* dres, float* dconv, const float* packed_bwd, const void* plan_bwd,
+                   int64_t Vin, int32_t Cin, int32_t K, float* din, lt_stream_t stream);
 
 /* ------------------------------------------------------------------ point <-> voxel
  * F.spvoxelize(feats, idx, counts)  (torchsparse_utils.py:20,23,54): out[idx[i]] += f[i]/counts[idx[i]] */

@@ -135,6 +135,33 @@ __global__ __launch_bounds__(64) void k_sum_partials(const float* __restrict__ p
   }
 }
 
+// statistics from the per-workgroup column sums a conv wrote (lt_spconv_plan_fwd_stats): partial[b][0][c] = sum x,
+// partial[b][1][c] = sum x^2.  One 256-thread block per channel, fp64 accumulation in a fixed order.
+__global__ __launch_bounds__(256) void k_bn_finalize_sums(const float* __restrict__ partial, int64_t nb, int64_t V, int C,
+                                                          float* __restrict__ mean, float* __restrict__ var) {
+  __shared__ double s1s[256], s2s[256];
+  const int c = blockIdx.x, t = threadIdx.x;
+  double s1 = 0.0, s2 = 0.0;
+  for (int64_t b = t; b < nb; b += 256) {
+    s1 += (double)partial[b * 2 * C + c];
+    s2 += (double)partial[b * 2 * C + C + c];
+  }
+  s1s[t] = s1;
+  s2s[t] = s2;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (t < off) { s1s[t] += s1s[t + off]; s2s[t] += s2s[t + off]; }
+    __syncthreads();
+  }
+  if (t == 0) {
+    const double m = s1s[0] / (double)V;
+    double v = s2s[0] / (double)V - m * m;
+    if (v < 0.0) v = 0.0;
+    mean[c] = (float)m;
+    var[c] = (float)v;
+  }
+}
+
 static int check_vc(const char* who, int64_t V, int32_t C) {
   LT_REQUIRE(V >= 1, LT_ERR_ARG, "%s: V=%lld must be >= 1", who, (long long)V);
   LT_REQUIRE(C >= 4 && C % 4 == 0 && C <= 1024, LT_ERR_ARG, "%s: C=%d must be a multiple of 4 in [4,1024]", who, C);
@@ -154,6 +181,16 @@ extern "C" int lt_bn_stats(const float* x, int64_t V, int32_t C, void* ws, int64
                      (float*)ws);
   LT_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_bn_finalize, dim3(C), dim3(64), 0, stream, (const float*)ws, nb, x, V, C, mean, var);
+  LT_LAUNCH_CHECK();
+  return LT_OK;
+}
+
+extern "C" int lt_bn_finalize_sums(const float* partial, int64_t nb, int64_t V, int32_t C, float* mean, float* var,
+                                   hipStream_t stream) {
+  int rc = check_vc("lt_bn_finalize_sums", V, C);
+  if (rc) return rc;
+  LT_REQUIRE(partial && mean && var && nb >= 1, LT_ERR_ARG, "lt_bn_finalize_sums: bad args");
+  hipLaunchKernelGGL(k_bn_finalize_sums, dim3(C), dim3(256), 0, stream, partial, nb, V, C, mean, var);
   LT_LAUNCH_CHECK();
   return LT_OK;
 }

@@ -275,6 +275,7 @@ struct PlanArgs {
   const int* torder;                  // [T] tiles by descending work
   float* out;
   int Vin, Vout, Cin, Cout, K;
+  float* partial;                     // optional [gridDim.x][2][Cout]: per-workgroup column sums of out and out^2
 };
 
 typedef __attribute__((address_space(3))) void* lt_lds_ptr;
@@ -601,6 +602,29 @@ __global__ __launch_bounds__(64 * W) void k_spconv_rf(PlanArgs a) {
       }
     }
   }
+  // BatchNorm statistics of the rows this workgroup produced (rows past Vout hold exact zeros): the conv output is
+  // not read again for them.  Fixed summation order -> deterministic.
+  if (a.partial) {
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int h = 0; h < SR; ++h)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const float v = acc[h][n][reg];
+          s1 += v;
+          s2 += v * v;
+        }
+      s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+      s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+      if (q == 0) {
+        float* p = a.partial + (int64_t)blockIdx.x * 2 * a.Cout + 16 * (nt0 + n) + r;
+        p[0] = s1;
+        p[a.Cout] = s2;
+      }
+    }
+  }
 }
 
 template <int SR, int NTW, int W>
@@ -638,10 +662,110 @@ static int launch_rf(const PlanArgs& a, int sr, hipStream_t stream) {
   return LT_OK;
 }
 
-// variant: 0 = default choice, otherwise 100*SR + NTW (tuning / tests)
+// ---------------------------------------------------------------------------------------------------------------------
+// Conv launch timer (bench.py's roofline leg): while armed, every sparse-conv kernel launch of this library is bracketed
+// by two hipEvents recorded on the stream the kernel is launched on.  Process-global, one caller thread (as everywhere).
+struct LtConvTimer {
+  hipEvent_t* ev = nullptr;  // 2 * cap
+  int32_t* meta = nullptr;   // 4 * cap: Cin, Cout, K, Vout
+  int cap = 0, n = 0, dropped = 0;
+  bool armed = false;
+};
+static LtConvTimer g_timer;
+
+struct LtConvTimerScope {
+  int slot = -1;
+  hipStream_t stream;
+  LtConvTimerScope(hipStream_t s, int Cin, int Cout, int K, int64_t Vout) : stream(s) {
+    if (!g_timer.armed) return;
+    if (g_timer.n >= g_timer.cap) { ++g_timer.dropped; return; }
+    slot = g_timer.n++;
+    int32_t* m = g_timer.meta + 4 * slot;
+    m[0] = Cin; m[1] = Cout; m[2] = K; m[3] = (int32_t)Vout;
+    (void)hipEventRecord(g_timer.ev[2 * slot], stream);
+  }
+  ~LtConvTimerScope() {
+    if (slot >= 0) (void)hipEventRecord(g_timer.ev[2 * slot + 1], stream);
+  }
+};
+
+extern "C" int lt_conv_timer_begin(int32_t capacity) {
+  LT_REQUIRE(capacity > 0 && capacity <= (1 << 20), LT_ERR_ARG, "lt_conv_timer_begin: capacity %d not in [1, 2^20]", capacity);
+  if (capacity > g_timer.cap) {
+    hipEvent_t* ev = (hipEvent_t*)realloc(g_timer.ev, sizeof(hipEvent_t) * 2 * capacity);
+    int32_t* meta = (int32_t*)realloc(g_timer.meta, sizeof(int32_t) * 4 * capacity);
+    LT_REQUIRE(ev && meta, LT_ERR_ARG, "lt_conv_timer_begin: out of host memory");
+    g_timer.ev = ev;
+    g_timer.meta = meta;
+    for (int i = 2 * g_timer.cap; i < 2 * capacity; ++i) LT_CHECK_HIP(hipEventCreate(&g_timer.ev[i]));
+    g_timer.cap = capacity;
+  }
+  g_timer.n = 0;
+  g_timer.dropped = 0;
+  g_timer.armed = true;
+  return LT_OK;
+}
+
+extern "C" int64_t lt_conv_timer_end(float* ms, int32_t* meta, int64_t capacity) {
+  g_timer.armed = false;
+  LT_REQUIRE(g_timer.dropped == 0, LT_ERR_RANGE, "lt_conv_timer_end: %d launches beyond the capacity given to lt_conv_timer_begin",
+             g_timer.dropped);
+  const int n = g_timer.n;
+  LT_REQUIRE(capacity >= n && (n == 0 || (ms && meta)), LT_ERR_ARG, "lt_conv_timer_end: room for %lld launches, %d recorded",
+             (long long)capacity, n);
+  for (int i = 0; i < n; ++i) {
+    LT_CHECK_HIP(hipEventSynchronize(g_timer.ev[2 * i + 1]));
+    LT_CHECK_HIP(hipEventElapsedTime(&ms[i], g_timer.ev[2 * i], g_timer.ev[2 * i + 1]));
+    for (int j = 0; j < 4; ++j) meta[4 * i + j] = g_timer.meta[4 * i + j];
+  }
+  g_timer.n = 0;
+  return n;
+}
+
+// default kernel shape: 2 column tiles per wave; the tallest workgroup (64, 32 or 16 rows) that still puts >= 10 000
+// waves on the chip -- a wave's slab chain is sequential, so coarse levels need short chains more than weight reuse
+// (measured on every level/width of the U-Net: tools/conv_bench.py)
+static void rf_default_shape(int64_t Vout, int Cout, int* sr, int* ntw) {
+  const int ntt = Cout / 16;
+  *ntw = ntt % 2 == 0 ? 2 : 1;
+  *sr = 1;
+  for (int c = 4; c >= 1; c >>= 1) {
+    const int64_t waves = ((Vout + 16 * c - 1) / (16 * c)) * (ntt / *ntw);
+    if (waves >= 10000) { *sr = c; break; }
+  }
+}
+static int64_t rf_grid_x(int64_t Vout, int sr) {
+  if (sr >= 4) return (Vout + 16 * sr - 1) / (16 * sr);
+  return ((Vout + LT_TM - 1) / LT_TM) * (4 / sr);
+}
+
+extern "C" int64_t lt_spconv_stat_blocks(int64_t Vout, int32_t Cout) {
+  int sr, ntw;
+  if (Vout <= 0 || Cout < 16) return 0;
+  rf_default_shape(Vout, Cout, &sr, &ntw);
+  return rf_grid_x(Vout, sr);
+}
+
+static int spconv_plan_impl(const float* in, const float* packed, const void* plan, float* out, int64_t Vin,
+                            int64_t Vout, int32_t Cin, int32_t Cout, int32_t K, int32_t variant, float* partial,
+                            hipStream_t stream);
+
 extern "C" int lt_spconv_plan_fwd_v(const float* in, const float* packed, const void* plan, float* out, int64_t Vin,
                                     int64_t Vout, int32_t Cin, int32_t Cout, int32_t K, int32_t variant,
                                     hipStream_t stream) {
+  return spconv_plan_impl(in, packed, plan, out, Vin, Vout, Cin, Cout, K, variant, nullptr, stream);
+}
+
+extern "C" int lt_spconv_plan_fwd_stats(const float* in, const float* packed, const void* plan, float* out, int64_t Vin,
+                                        int64_t Vout, int32_t Cin, int32_t Cout, int32_t K, float* partial,
+                                        hipStream_t stream) {
+  LT_REQUIRE(partial, LT_ERR_ARG, "lt_spconv_plan_fwd_stats: partial is null");
+  return spconv_plan_impl(in, packed, plan, out, Vin, Vout, Cin, Cout, K, 0, partial, stream);
+}
+
+static int spconv_plan_impl(const float* in, const float* packed, const void* plan, float* out, int64_t Vin,
+                            int64_t Vout, int32_t Cin, int32_t Cout, int32_t K, int32_t variant, float* partial,
+                            hipStream_t stream) {
   LT_REQUIRE(Vin >= 0 && Vout >= 0 && Vin < INT32_MAX && Vout < INT32_MAX, LT_ERR_RANGE, "lt_spconv_plan_fwd: bad row counts");
   LT_REQUIRE(K >= 1 && K <= LT_KMAX, LT_ERR_ARG, "lt_spconv_plan_fwd: kernel volume %d not in [1,%d]", K, LT_KMAX);
   LT_REQUIRE(Cin >= 16 && Cin % 16 == 0, LT_ERR_ARG, "lt_spconv_plan_fwd: Cin=%d must be a multiple of 16", Cin);
@@ -650,17 +774,12 @@ extern "C" int lt_spconv_plan_fwd_v(const float* in, const float* packed, const 
   LT_REQUIRE(packed && plan && out && (Vin == 0 || in), LT_ERR_ARG, "lt_spconv_plan_fwd: null pointer");
   LT_REQUIRE(((uintptr_t)plan & 15) == 0, LT_ERR_ARG, "lt_spconv_plan_fwd: plan must be 16-byte aligned");
   LtPlanView pv = lt_plan_view(const_cast<void*>(plan), K, Vout);
-  PlanArgs a{in, packed, pv.tnbr, pv.tmask, pv.order, pv.torder, out, (int)Vin, (int)Vout, Cin, Cout, K};
+  PlanArgs a{in, packed, pv.tnbr, pv.tmask, pv.order, pv.torder, out, (int)Vin, (int)Vout, Cin, Cout, K, partial};
+  LtConvTimerScope timed(stream, Cin, Cout, K, Vout);
   const int ntt = Cout / 16;
-  // default: 2 column tiles per wave; the tallest workgroup (64, 32 or 16 rows) that still puts >= 10 000 waves on the
-  // chip -- a wave's slab chain is sequential, so coarse levels need short chains more than weight reuse (measured on
-  // every level/width of the U-Net: tools/conv_bench.py)
-  int ntw = ntt % 2 == 0 ? 2 : 1;
-  int sr = 1;
-  for (int c = 4; c >= 1; c >>= 1) {
-    const int64_t waves = ((Vout + 16 * c - 1) / (16 * c)) * (ntt / ntw);
-    if (waves >= 10000) { sr = c; break; }
-  }
+  int sr, ntw;
+  rf_default_shape(Vout, Cout, &sr, &ntw);
+  LT_REQUIRE(!(partial && variant != 0), LT_ERR_ARG, "lt_spconv_plan_fwd: statistics need the default variant");
   if (variant == 1) {  // the LDS-DMA staged kernel
     if (ntt % 8 == 0) return launch_plan<8, 2>(a, stream);
     if (ntt % 6 == 0) return launch_plan<6, 2>(a, stream);
@@ -704,6 +823,7 @@ extern "C" int lt_spconv_fwd(const float* in, const float* packed, const int32_t
   if (Vout == 0) return LT_OK;
   LT_REQUIRE(packed && nbr && out && (Vin == 0 || in), LT_ERR_ARG, "lt_spconv_fwd: null pointer");
   ConvArgs a{in, packed, nbr, order, out, (int)Vin, (int)Vout, Cin, Cout, K};
+  LtConvTimerScope timed(stream, Cin, Cout, K, Vout);
   const int ntt = Cout / 16;
   // widest accumulator strip (<= 8 tiles = 128 channels) that divides the channel-tile count
   if (ntt % 8 == 0) return launch_conv<8>(a, stream);

@@ -11,7 +11,7 @@ from torch.autograd import Function
 
 from . import ops
 
-__all__ = ["KernelMap", "get_kernel_offsets", "sparse_conv", "batch_norm", "spvoxelize", "spdevoxelize"]
+__all__ = ["KernelMap", "get_kernel_offsets", "sparse_conv", "conv_bn", "batch_norm", "spvoxelize", "spdevoxelize"]
 
 _OFFSET_CACHE: dict = {}
 
@@ -207,6 +207,56 @@ class _BatchNorm(Function):
         dx, dgamma, dbeta, dres = ops.bn_bwd(dy, x, y, mean, var, gamma, ctx.eps, ctx.relu, need_dx=need_dx,
                                              need_dres=need_dres)
         return dx, dgamma, dbeta, dres, None, None, None
+
+
+class _ConvBN(Function):
+    """y = relu(bn(conv(feats)) + residual) as ONE autograd node over the composite entry points lt_conv_bn_fwd/bwd
+    (frozen conv kernel: the norm-only TTA configuration; anything else takes the unfused ops)."""
+
+    @staticmethod
+    def forward(ctx, feats, weight, gamma, beta, residual, kmap, transposed, relu, eps, wcache):
+        w = weight if weight.dim() == 3 else weight.unsqueeze(0)
+        cin, cout = w.shape[1], w.shape[2]
+        packed = _packed(weight, 0, wcache)
+        if ops.CONV_PAIRS is not None:
+            if kmap._npairs is None:
+                kmap._npairs = (kmap.results >= 0).sum()
+            ops.CONV_PAIRS.append(kmap._npairs)
+        n_out = kmap.n_in if transposed else kmap.n_out
+        plan = kmap.reverse_plan() if transposed else kmap.plan()
+        conv_out, y, mean, var = ops.conv_bn_fwd(feats, packed, plan, kmap.K, n_out, cout, gamma.detach(), beta.detach(),
+                                                 eps, residual, relu)
+        ctx.kmap, ctx.transposed, ctx.relu, ctx.eps, ctx.wcache = kmap, transposed, relu, eps, wcache
+        ctx.cin, ctx.n_in = cin, feats.shape[0]
+        ctx.has_res = residual is not None
+        ctx.save_for_backward(conv_out, y if relu else None, mean, var, gamma, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        conv_out, y, mean, var, gamma, weight = ctx.saved_tensors
+        kmap, transposed = ctx.kmap, ctx.transposed
+        dy = dy.contiguous()
+        packed_bwd = plan_bwd = None
+        if ctx.needs_input_grad[0]:
+            if ops.CONV_PAIRS is not None:
+                ops.CONV_PAIRS.append(kmap._npairs)
+            if kmap.submanifold and not transposed:
+                packed_bwd, plan_bwd = _packed(weight, 2, ctx.wcache), kmap.plan()
+            elif not transposed:
+                packed_bwd, plan_bwd = _packed(weight, 1, ctx.wcache), kmap.reverse_plan()
+            else:
+                packed_bwd, plan_bwd = _packed(weight, 1, ctx.wcache), kmap.plan()
+        need_dres = ctx.has_res and ctx.needs_input_grad[4]
+        din, dgamma, dbeta, dres = ops.conv_bn_bwd(dy, conv_out, y, mean, var, gamma.detach(), ctx.eps, ctx.relu, need_dres,
+                                                   packed_bwd, plan_bwd, kmap.K, ctx.n_in, ctx.cin)
+        return din, None, dgamma, dbeta, dres, None, None, None, None, None
+
+
+def conv_bn(feats, weight, gamma, beta, kmap: KernelMap, transposed=False, residual=None, relu=False, eps=1e-5,
+            wcache=None):
+    return _ConvBN.apply(feats.contiguous(), weight, gamma, beta, residual, kmap, bool(transposed), bool(relu),
+                         float(eps), wcache)
 
 
 def batch_norm(x, gamma, beta, eps=1e-5, residual=None, relu=False, stats_out=None):

@@ -190,9 +190,26 @@ def pack_weights(weight: torch.Tensor, mode: int = 0) -> torch.Tensor:
     return packed
 
 
-# bench.py's kernel timer: when a list, every spconv launch appends (start event, end event, Cin, Cout, K, Vout).
-# Events are recorded on torch's current stream, which is the stream the kernel is launched on.
-CONV_TRACE = None
+def conv_timer_begin(capacity: int) -> None:
+    """bench.py's kernel timer: until conv_timer_end() the library brackets every sparse-conv kernel launch with two HIP
+    events on the stream the kernel is launched on (lt_conv_timer_begin)."""
+    _lib.call("lt_conv_timer_begin", int(capacity))
+
+
+def conv_timer_end():
+    """-> (ms float32 [n], meta int32 [n,4] = Cin, Cout, K, Vout), one row per conv kernel launch since conv_timer_begin."""
+    import numpy as np
+    lib = _lib.load()
+    cap = 1 << 20
+    ms = np.empty(cap, dtype=np.float32)
+    meta = np.empty((cap, 4), dtype=np.int32)
+    n = lib.lt_conv_timer_end(ms.ctypes.data_as(ctypes.c_void_p), meta.ctypes.data_as(ctypes.c_void_p), cap)
+    if n < 0:
+        msg = lib.lt_last_error()
+        raise _lib.LatteHipError(f"lt_conv_timer_end failed (rc={n}): {msg.decode() if msg else ''}")
+    return ms[:n].copy(), meta[:n].copy()
+
+
 # bench.py's flop counter (untimed pass): when a list, every spconv call appends its pair count (device scalar).
 CONV_PAIRS = None
 
@@ -211,14 +228,8 @@ def spconv(feats: torch.Tensor, packed: torch.Tensor, nbr: torch.Tensor, cout: i
         order = _chk(order, torch.int32, "spconv order")
         assert order.numel() == Vout
     out = torch.empty((Vout, cout), dtype=torch.float32, device=feats.device)
-    if CONV_TRACE is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
     _lib.call("lt_spconv_fwd", _p(feats), _p(packed), _p(nbr), _p(order), _p(out), Vin, Vout, Cin, int(cout), K,
               _stream())
-    if CONV_TRACE is not None:
-        e1.record()
-        CONV_TRACE.append((e0, e1, Cin, int(cout), K, Vout))
     return out
 
 
@@ -234,14 +245,8 @@ def spconv_plan(feats: torch.Tensor, packed: torch.Tensor, plan: torch.Tensor, K
     if packed.numel() != K * Cin * cout:
         raise ValueError(f"spconv: packed weights have {packed.numel()} floats, expected {K}*{Cin}*{cout}")
     out = torch.empty((Vout, cout), dtype=torch.float32, device=feats.device)
-    if CONV_TRACE is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
     _lib.call("lt_spconv_plan_fwd_v", _p(feats), _p(packed), _p(plan), _p(out), Vin, Vout, Cin, int(cout), K,
               int(CONV_VARIANT if variant is None else variant), _stream())
-    if CONV_TRACE is not None:
-        e1.record()
-        CONV_TRACE.append((e0, e1, Cin, int(cout), K, Vout))
     return out
 
 
@@ -465,3 +470,39 @@ def class_median_mask(vals, label, num_classes: int, cap: float):
     _lib.call("lt_class_median_mask", _p(vals), _p(label), n, int(num_classes), float(cap), _p(ws), ws.numel(), _p(keep),
               _stream())
     return keep.bool()
+
+
+# ------------------------------------------------------------------ conv -> BN [+ residual] [+ ReLU] composites
+def conv_bn_fwd(feats, packed, plan, K: int, Vout: int, cout: int, gamma, beta, eps: float, residual, relu: bool):
+    """-> (conv_out, y, mean, var).  One host call (lt_conv_bn_fwd): conv with statistics epilogue, finalize, BN apply."""
+    Vin, Cin = feats.shape
+    dev = feats.device
+    lib = _lib.load()
+    conv_out = torch.empty((Vout, cout), dtype=torch.float32, device=dev)
+    y = torch.empty((Vout, cout), dtype=torch.float32, device=dev)
+    stats = torch.empty((2, cout), dtype=torch.float32, device=dev)
+    ws = _ws(lib.lt_conv_bn_workspace_bytes(Vout, cout), dev)
+    mean, var = stats[0], stats[1]
+    _lib.call("lt_conv_bn_fwd", _p(feats), _p(packed), _p(plan), Vin, Vout, Cin, int(cout), K, _p(gamma), _p(beta),
+              float(eps), _p(residual), int(relu), _p(ws), ws.numel(), _p(conv_out), _p(y), _p(mean), _p(var), _stream())
+    return conv_out, y, mean, var
+
+
+def conv_bn_bwd(dy, conv_out, y, mean, var, gamma, eps: float, relu: bool, need_dres: bool, packed_bwd, plan_bwd,
+                K: int, Vin: int, cin: int):
+    """-> (din | None, dgamma, dbeta, dres | None); din is computed when packed_bwd is given."""
+    Vout, cout = conv_out.shape
+    dev = conv_out.device
+    lib = _lib.load()
+    ws = _ws(lib.lt_conv_bn_workspace_bytes(Vout, cout), dev)
+    dgb = torch.empty((2, cout), dtype=torch.float32, device=dev)
+    dgamma, dbeta = dgb[0], dgb[1]
+    dres = torch.empty_like(conv_out) if need_dres else None
+    need_din = packed_bwd is not None
+    dconv = torch.empty_like(conv_out) if need_din else None
+    din = torch.empty((Vin, cin), dtype=torch.float32, device=dev) if need_din else None
+    yp = _p(y) if relu else None
+    _lib.call("lt_conv_bn_bwd", _p(dy), _p(conv_out), yp, _p(mean), _p(var), _p(gamma), float(eps), int(relu), Vout,
+              cout, _p(ws), ws.numel(), _p(dgamma), _p(dbeta), _p(dres), _p(dconv), _p(packed_bwd), _p(plan_bwd),
+              Vin, cin, K, _p(din), _stream())
+    return din, dgamma, dbeta, dres

@@ -9,7 +9,7 @@ from . import functional as LF
 from . import ops
 from .tensor import PointTensor, SparseTensor
 
-__all__ = ["initial_voxelize", "point_to_voxel", "voxel_to_point"]
+__all__ = ["initial_voxelize", "point_to_voxel", "voxel_to_point", "p2v_index", "v2p_index"]
 
 
 def initial_voxelize(z: PointTensor, init_res: float, after_res: float, cache: dict | None = None) -> SparseTensor:
@@ -36,6 +36,10 @@ def initial_voxelize(z: PointTensor, init_res: float, after_res: float, cache: d
     new_tensor.cmaps.setdefault(new_tensor.stride, new_tensor.coords)
     z.additional_features["idx_query"][1] = idx_query
     z.additional_features["counts"][1] = counts
+    # torchsparse strides are ints, ours are 3-tuples: register the map under both so that point_to_voxel at stride 1
+    # finds it (same map: the stride-1 cells ARE the voxels of x0) instead of rebuilding it by a hash query
+    z.additional_features["idx_query"].setdefault(new_tensor.stride, idx_query)
+    z.additional_features["counts"].setdefault(new_tensor.stride, counts)
     z.C = new_float_coord
     return new_tensor
 
@@ -44,7 +48,8 @@ def _cell_coords(z: PointTensor, s: int) -> torch.Tensor:
     return torch.cat([torch.floor(z.C[:, :3] / s).int() * s, z.C[:, -1].int().view(-1, 1)], 1).contiguous()
 
 
-def point_to_voxel(x: SparseTensor, z: PointTensor) -> SparseTensor:
+def p2v_index(x: SparseTensor, z: PointTensor):
+    """point -> voxel map of stride x.s (cached on z.additional_features)."""
     af = z.additional_features
     if af is None or af.get("idx_query") is None or af["idx_query"].get(x.s) is None:
         pc_hash = ops.sphash(_cell_coords(z, x.s[0]))
@@ -53,24 +58,33 @@ def point_to_voxel(x: SparseTensor, z: PointTensor) -> SparseTensor:
         counts = ops.spcount(idx_query.int(), x.C.shape[0])
         af["idx_query"][x.s] = idx_query
         af["counts"][x.s] = counts
-    else:
-        idx_query, counts = af["idx_query"][x.s], af["counts"][x.s]
+    return af["idx_query"][x.s], af["counts"][x.s]
+
+
+def point_to_voxel(x: SparseTensor, z: PointTensor) -> SparseTensor:
+    idx_query, counts = p2v_index(x, z)
     new_tensor = SparseTensor(LF.spvoxelize(z.F, idx_query, counts), x.C, x.s)
     new_tensor.cmaps, new_tensor.kmaps = x.cmaps, x.kmaps
     return new_tensor
 
 
+def v2p_index(x: SparseTensor, z: PointTensor, nearest: bool = False):
+    """8-corner voxel ids and trilinear weights of every point at stride x.s -> ([N,8] int64, [N,8] fp32)."""
+    off = LF.get_kernel_offsets(2, x.s, 1, device=z.C.device)
+    old_hash = ops.sphash(_cell_coords(z, x.s[0]), off)
+    pc_hash = ops.sphash(x.C.int().contiguous())
+    idx_query = ops.sphashquery(old_hash, pc_hash)  # [8, N]
+    weights = ops.calc_ti_weights(z.C.float().contiguous(), idx_query, x.s[0]).transpose(0, 1).contiguous()
+    idx_query = idx_query.transpose(0, 1).contiguous()
+    if nearest:
+        weights[:, 1:] = 0.0
+        idx_query[:, 1:] = -1
+    return idx_query, weights
+
+
 def voxel_to_point(x: SparseTensor, z: PointTensor, nearest: bool = False) -> PointTensor:
     if z.idx_query is None or z.weights is None or z.idx_query.get(x.s) is None or z.weights.get(x.s) is None:
-        off = LF.get_kernel_offsets(2, x.s, 1, device=z.F.device)
-        old_hash = ops.sphash(_cell_coords(z, x.s[0]), off)
-        pc_hash = ops.sphash(x.C.int().contiguous())
-        idx_query = ops.sphashquery(old_hash, pc_hash)  # [8, N]
-        weights = ops.calc_ti_weights(z.C.float().contiguous(), idx_query, x.s[0]).transpose(0, 1).contiguous()
-        idx_query = idx_query.transpose(0, 1).contiguous()
-        if nearest:
-            weights[:, 1:] = 0.0
-            idx_query[:, 1:] = -1
+        idx_query, weights = v2p_index(x, z, nearest)
         new_feat = LF.spdevoxelize(x.F, idx_query, weights)
         new_tensor = PointTensor(new_feat, z.C, idx_query=z.idx_query, weights=z.weights)
         new_tensor.additional_features = z.additional_features

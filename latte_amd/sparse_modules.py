@@ -14,7 +14,7 @@ from . import functional as LF
 from . import ops
 from .tensor import SparseTensor
 
-__all__ = ["Conv3d", "BatchNorm", "ReLU", "conv3d", "build_kernel_map"]
+__all__ = ["Conv3d", "BatchNorm", "ReLU", "conv3d", "conv3d_bn", "build_kernel_map"]
 
 
 def _n3(v):
@@ -75,6 +75,28 @@ def conv3d(input: SparseTensor, weight, bias=None, kernel_size=3, stride=1, dila
         if bias is not None:
             out_feats = out_feats + bias
         output = SparseTensor(out_feats, input.cmaps[tensor_stride], tensor_stride)
+    output.cmaps = input.cmaps
+    output.cmaps.setdefault(output.stride, output.coords)
+    output.kmaps = input.kmaps
+    return output
+
+
+def conv3d_bn(input: SparseTensor, conv: "Conv3d", bn: "BatchNorm", relu: bool, residual=None):
+    """conv3d + BatchNorm(batch statistics) [+ residual] [+ ReLU] as one composite op (see functional._ConvBN); same
+    kernel-map / output-coordinate logic as conv3d.  Returns None when the output would have a single row (BN refuses)."""
+    ks, st, dl = conv.kernel_size, conv.stride, conv.dilation
+    if not conv.transposed:
+        kmap, out_coords = build_kernel_map(input, ks, st, dl)
+        out_stride = tuple(input.stride[k] * st[k] for k in range(3))
+    else:
+        out_stride = tuple(input.stride[k] // st[k] for k in range(3))
+        kmap = input.kmaps[(out_stride, ks, st, dl)]
+        out_coords = input.cmaps[out_stride]
+    if out_coords.shape[0] < 2:
+        return None
+    feats = LF.conv_bn(input.feats, conv.kernel, bn.weight, bn.bias, kmap, conv.transposed, residual=residual, relu=relu,
+                       eps=bn.eps, wcache=conv._packed_cache)
+    output = SparseTensor(feats, out_coords, out_stride)
     output.cmaps = input.cmaps
     output.cmaps.setdefault(output.stride, output.coords)
     output.kmaps = input.kmaps

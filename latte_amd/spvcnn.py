@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from . import sparse_modules as spnn
-from .point_voxel import initial_voxelize, point_to_voxel, voxel_to_point
+from .point_voxel import initial_voxelize, p2v_index, point_to_voxel, v2p_index, voxel_to_point
 from .tensor import PointTensor, SparseTensor, cat
 
 __all__ = ["SPVCNN", "Net3DSeg", "BasicConvolutionBlock", "BasicDeconvolutionBlock", "ResidualBlock",
@@ -19,9 +19,19 @@ __all__ = ["SPVCNN", "Net3DSeg", "BasicConvolutionBlock", "BasicDeconvolutionBlo
 
 
 def _conv_bn(seq, x: SparseTensor, i: int, relu: bool, residual=None) -> SparseTensor:
-    """seq[i] = Conv3d, seq[i+1] = BatchNorm: conv, then the fused BN(+residual)(+ReLU) kernel."""
-    y = seq[i](x)
-    y.feats = seq[i + 1].bn_feats(y.feats, residual=residual, relu=relu)
+    """seq[i] = Conv3d, seq[i+1] = BatchNorm.  Hot case (frozen kernel, batch statistics, Cin % 16 == 0, on the GPU): one
+    composite call -- conv with the BN statistics in its epilogue, finalize, BN(+residual)(+ReLU).  Otherwise conv, then
+    the fused BN(+residual)(+ReLU) kernel."""
+    conv, bn = seq[i], seq[i + 1]
+    batch_stats = bn.training or not bn.track_running_stats or bn.running_mean is None
+    updates_running = bn.training and bn.track_running_stats and bn.running_mean is not None
+    if (conv.kernel_volume > 1 and conv.bias is None and x.feats.is_cuda and x.feats.shape[1] % 16 == 0
+            and batch_stats and not updates_running and not conv.kernel.requires_grad and x.feats.shape[0] > 1):
+        y = spnn.conv3d_bn(x, conv, bn, relu=relu, residual=residual)
+        if y is not None:
+            return y
+    y = conv(x)
+    y.feats = bn.bn_feats(y.feats, residual=residual, relu=relu)
     return y
 
 
@@ -127,9 +137,10 @@ class SPVCNN(nn.Module):
         y = up[0](y)
         return up[1](cat([y, skip]))
 
-    def forward(self, x: SparseTensor) -> torch.Tensor:
-        # index structures (voxel sets, point<->voxel maps, kernel maps, conv plans) depend on x.C only: they are built
-        # by the first forward over a batch and reused by later ones (teacher then student see the same `lidar`)
+    @staticmethod
+    def _batch_cache(x: SparseTensor):
+        """index structures (voxel sets, point<->voxel maps, kernel maps, conv plans) depend on x.C only: they are built
+        by the first pass over a batch and reused by later ones (teacher then student see the same `lidar`)"""
         cache = getattr(x, "_lt_cache", None)
         if cache is None or cache.get("coords_ptr") != (x.C.data_ptr(), tuple(x.C.shape)):
             cache = {"coords_ptr": (x.C.data_ptr(), tuple(x.C.shape)), "point": None}
@@ -139,6 +150,38 @@ class SPVCNN(nn.Module):
             cache["point"] = (z.idx_query, z.weights, z.additional_features)
         else:
             z.idx_query, z.weights, z.additional_features = cache["point"]
+        return cache, z
+
+    @torch.no_grad()
+    def prepare(self, x: SparseTensor) -> None:
+        """Build every index structure the forward AND backward over this batch will need (no feature work): the voxel
+        set of each level, the 3^3 map and plan of each level, the 2^3 stride-2 maps with forward and reverse plans, the
+        point<->voxel maps of strides 1, 4 and 16.  After this, forwards over the batch only launch feature kernels and
+        may run concurrently on different streams (LatteStep runs teacher and student side by side)."""
+        cache, z = self._batch_cache(x)
+        if cache.get("prepared"):
+            return
+        t = initial_voxelize(z, self.pres, self.vres, cache)
+        levels = {1: t}
+        for s in (1, 2, 4, 8):
+            km3, _ = spnn.build_kernel_map(t, 3, 1, 1)
+            km3.plan()
+            km2, oc = spnn.build_kernel_map(t, 2, 2, 1)
+            km2.plan()
+            km2.reverse_plan()
+            nt = SparseTensor(t.feats[:0], oc, 2 * s)
+            nt.cmaps, nt.kmaps = t.cmaps, t.kmaps
+            nt.cmaps.setdefault(nt.stride, oc)
+            t = levels[2 * s] = nt
+        spnn.build_kernel_map(t, 3, 1, 1)[0].plan()
+        for s in (1, 16, 4):  # the order the forward asks for them
+            if z.idx_query.get(levels[s].s) is None:
+                z.idx_query[levels[s].s], z.weights[levels[s].s] = v2p_index(levels[s], z)
+            p2v_index(levels[s], z)
+        cache["prepared"] = True
+
+    def forward(self, x: SparseTensor) -> torch.Tensor:
+        cache, z = self._batch_cache(x)
         x0 = self._stem(initial_voxelize(z, self.pres, self.vres, cache))
         z0 = voxel_to_point(x0, z, nearest=False)
 

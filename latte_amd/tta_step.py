@@ -112,7 +112,7 @@ def shard_scan_offset(rank: int, scans_per_rank: int) -> int:
 class LatteStep:
     def __init__(self, model_3d: nn.Module, num_classes: int, hr_cfg: Dict, lr: float = 1e-3, conf_perc=None,
                  lambda_hr_23: float = 0.3, lambda_hr_32: float = 0.3, lambda_ety_ps: float = 1.0, class_weights=None,
-                 process_group=None):
+                 process_group=None, overlap: bool = True):
         self.model = configure_model_norm(model_3d, reset_dropout=True)
         self.ema_model = create_ema_model(self.model)
         self.hr = HR_Block(**hr_cfg)
@@ -126,6 +126,8 @@ class LatteStep:
         self.pg = process_group
         self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
         self.timers = None
+        self.overlap = overlap      # teacher and student forward on two streams (same results, see forward_backward)
+        self._streams = None
 
     # -------------------------------------------------------------------------------------------------
     def _tick(self, name: str):
@@ -146,16 +148,40 @@ class LatteStep:
             self._t_last = time.perf_counter()
         extra = {k: batch[k] for k in ("pose", "scene_name", "scan_ID", "img_indices")}
         pc2img = batch["pc2img_idx"]
-        with torch.no_grad():
-            ema3d = self.ema_model(batch)
-            ema3d["seg_logit"] = inverse_to_all(ema3d["seg_logit"], batch)
-            pc2img_mask, ema_logit_3d = pc2img_logit(ema3d["seg_logit"], pc2img)
-        self._tick("teacher_fwd")
         ema_logit_2d = batch["logit_2d_teacher"]
         preds_2d = {"seg_logit": batch["logit_2d_student"]}
-        preds_3d = self.model(batch)
-        preds_3d["seg_logit"] = inverse_to_all(preds_3d["seg_logit"], batch)
-        self._tick("student_fwd")
+        if self.overlap and self.timers is None:
+            # index structures once, then teacher and student forward side by side on two HIP streams: the two passes
+            # are independent, and most of their kernels (BN, point<->voxel, coarse-level convs) are far too small to
+            # fill 256 CUs on their own
+            self.model.net_3d.prepare(batch["lidar"])
+            main = torch.cuda.current_stream()
+            if self._streams is None:
+                self._streams = (torch.cuda.Stream(), torch.cuda.Stream())
+            s_t, s_s = self._streams
+            s_t.wait_stream(main)
+            s_s.wait_stream(main)
+            with torch.cuda.stream(s_t), torch.no_grad():
+                ema3d = self.ema_model(batch)
+                ema3d["seg_logit"] = inverse_to_all(ema3d["seg_logit"], batch)
+            with torch.cuda.stream(s_s):
+                preds_3d = self.model(batch)
+                preds_3d["seg_logit"] = inverse_to_all(preds_3d["seg_logit"], batch)
+            main.wait_stream(s_t)
+            main.wait_stream(s_s)
+            for t in (ema3d["seg_logit"], preds_3d["seg_logit"]):
+                t.record_stream(main)
+            with torch.no_grad():
+                pc2img_mask, ema_logit_3d = pc2img_logit(ema3d["seg_logit"], pc2img)
+        else:
+            with torch.no_grad():
+                ema3d = self.ema_model(batch)
+                ema3d["seg_logit"] = inverse_to_all(ema3d["seg_logit"], batch)
+                pc2img_mask, ema_logit_3d = pc2img_logit(ema3d["seg_logit"], pc2img)
+            self._tick("teacher_fwd")
+            preds_3d = self.model(batch)
+            preds_3d["seg_logit"] = inverse_to_all(preds_3d["seg_logit"], batch)
+            self._tick("student_fwd")
 
         ori_2d = [p[m] for p, m in zip(batch["ori_points"], pc2img)]
         a2 = dict(preds_2d, ori_points=ori_2d, **extra)

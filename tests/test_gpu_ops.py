@@ -261,6 +261,65 @@ def test_batchnorm_fwd_bwd_matches_torch(V, C, relu, res):
             assert rel_err(dres.cpu(), r.grad) < 1e-6
 
 
+@pytest.mark.parametrize("cin,cout", [(32, 32), (96, 48), (64, 256), (128, 80)])
+@pytest.mark.parametrize("ks,stride,transposed", [(3, 1, False), (2, 2, False), (2, 2, True)])
+@pytest.mark.parametrize("relu,res", [(False, False), (True, True)])
+def test_conv_bn_composite_matches_unfused_ops(scans_small, cin, cout, ks, stride, transposed, relu, res):
+    """lt_conv_bn_fwd / lt_conv_bn_bwd (BN statistics from the conv epilogue) against conv -> bn_stats -> bn_apply and
+    their backward: the conv output bitwise, statistics / BN output / gradients to fp32 rounding.  Also with bench.py's
+    conv launch timer armed."""
+    from latte_amd import ops
+    from latte_amd import functional as LF
+    c = scans_small["coords"]
+    _, _, out_coords, results = ts_ref.build_kmap(c, 1, ks, stride)
+    nbr = dev(results, torch.int32)
+    kmap = LF.KernelMap(nbr, c.shape[0], out_coords.shape[0], submanifold=(stride == 1))
+    K = results.shape[0]
+    g = torch.Generator().manual_seed(cin * 3 + cout + ks)
+    n_in = out_coords.shape[0] if transposed else c.shape[0]
+    n_out = c.shape[0] if transposed else out_coords.shape[0]
+    w = (torch.randn(K, cin, cout, generator=g) / np.sqrt(cin)).cuda()
+    gamma = (torch.rand(cout, generator=g) + 0.5).cuda().requires_grad_(True)
+    beta = torch.randn(cout, generator=g).cuda().requires_grad_(True)
+    x = torch.randn(n_in, cin, generator=g).cuda().requires_grad_(True)
+    r = torch.randn(n_out, cout, generator=g).cuda().requires_grad_(True) if res else None
+    dy = torch.randn(n_out, cout, generator=g).cuda()
+    eps = 1e-5
+
+    def unfused():
+        conv = LF.sparse_conv(x, w, kmap, transposed=transposed)
+        y = LF.batch_norm(conv, gamma, beta, eps, residual=r, relu=relu)
+        grads = torch.autograd.grad(y, [x, gamma, beta] + ([r] if res else []), dy)
+        return conv.detach(), y.detach(), grads
+
+    def fused():
+        y = LF.conv_bn(x, w, gamma, beta, kmap, transposed=transposed, residual=r, relu=relu, eps=eps)
+        grads = torch.autograd.grad(y, [x, gamma, beta] + ([r] if res else []), dy)
+        return y.detach(), grads
+
+    conv_u, y_u, g_u = unfused()
+    for trace in (False, True):
+        if trace:
+            ops.conv_timer_begin(8)
+        y_f, g_f = fused()
+        if trace:
+            ms, meta = ops.conv_timer_end()   # the library's conv launch timer sees the two kernels of the composites
+            n_out_rows = y_f.shape[0]
+            assert meta.tolist() == [[cin, cout, K, n_out_rows], [cout, cin, K, n_in]] and (ms > 0).all()
+        assert torch.allclose(y_f, y_u, rtol=1e-4, atol=1e-4), float((y_f - y_u).abs().max())
+        assert rel_err(y_f, y_u) < 1e-5
+        for a, b, name in zip(g_f, g_u, ("dx", "dgamma", "dbeta", "dres")):
+            assert rel_err(a, b) < 2e-4, (name, rel_err(a, b))
+    # the epilogue's per-workgroup partial sums against a float64 reduction of the conv output
+    plan = kmap.reverse_plan() if transposed else kmap.plan()
+    conv_o, y_o, mean, var = ops.conv_bn_fwd(x.detach(), ops.pack_weights(w, 0), plan, K, n_out, cout, gamma.detach(),
+                                             beta.detach(), eps, None, False)
+    assert torch.equal(conv_o, conv_u)
+    c64 = conv_u.double()
+    assert torch.allclose(mean.double(), c64.mean(0), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(var.double(), c64.var(0, unbiased=False), rtol=1e-4, atol=1e-7)
+
+
 def test_voxelize_devoxelize_match_oracle(scans_small):
     from latte_amd import ops
     c = scans_small["coords"]
