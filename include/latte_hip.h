@@ -119,16 +119,21 @@ int lt_spconv_fwd(const float* in, const float* packed, const int32_t* nbr, cons
  * Cout % 16 == 0.  Bitwise equal to lt_spconv_fwd. */
 int lt_spconv_plan_fwd(const float* in, const float* packed, const void* plan, float* out, int64_t Vin, int64_t Vout,
                        int32_t Cin, int32_t Cout, int32_t K, lt_stream_t stream);
-/* the same with an explicit kernel variant (tuning and tests): 0 = default, 1 = LDS-DMA staged kernel,
- * 100*SR + NTW = register-fed kernel with SR (1|2|4|8) 16-row strips per workgroup and NTW (1|2|4) column tiles per wave */
+/* the same with an explicit kernel variant (tuning and tests): 0 = default (split-k shape chosen from Vout, Cout),
+ * 1 = LDS-DMA staged kernel, 100*SR + NTW = register-fed kernel, one k-ascending chain per output element (bitwise equal
+ * to lt_spconv_fwd), SR (1|2|4|8) 16-row strips per workgroup, NTW (1|2|4) column tiles per wave;
+ * 1000 + 100*SR + 10*NTW + W = split-k: W (2|4|8) waves share the slab list of SR (1|2|4) strips x NTW (1|2|3|4|6|8)
+ * column tiles and add their partial sums in wave order (deterministic; differs from the single chain by fp32 rounding) */
 int lt_spconv_plan_fwd_v(const float* in, const float* packed, const void* plan, float* out, int64_t Vin, int64_t Vout,
                          int32_t Cin, int32_t Cout, int32_t K, int32_t variant, lt_stream_t stream);
-/* lt_spconv_plan_fwd that also writes, per workgroup b of the launch, the column sums of its output rows:
- * partial[(b*2+0)*Cout + c] = sum out[:,c], partial[(b*2+1)*Cout + c] = sum out[:,c]^2, b < lt_spconv_stat_blocks(Vout,Cout)
- * -- the BatchNorm statistics of the following spnn.BatchNorm (basic_blocks.py:22,40,56) without re-reading the output. */
+/* lt_spconv_plan_fwd that also leaves, in stats_ws (lt_spconv_stats_bytes), the column sums of the rows each workgroup b
+ * produced: partial[(b*2+0)*Cout + c] = sum out[:,c], partial[(b*2+1)*Cout + c] = sum out[:,c]^2 at the start of
+ * stats_ws, b < lt_spconv_stat_blocks(Vout,Cout) -- the BatchNorm statistics of the following spnn.BatchNorm
+ * (basic_blocks.py:22,40,56) without re-reading the output; lt_bn_finalize_sums turns them into mean / variance. */
 int64_t lt_spconv_stat_blocks(int64_t Vout, int32_t Cout);
+int64_t lt_spconv_stats_bytes(int64_t Vout, int32_t Cout);
 int lt_spconv_plan_fwd_stats(const float* in, const float* packed, const void* plan, float* out, int64_t Vin, int64_t Vout,
-                             int32_t Cin, int32_t Cout, int32_t K, float* partial, lt_stream_t stream);
+                             int32_t Cin, int32_t Cout, int32_t K, void* stats_ws, lt_stream_t stream);
 
 /* Conv launch timer -- measurement aid, no counterpart in the reference (bench.py's roofline leg uses it).  Between
  * begin and end every sparse-conv kernel launch of this library (lt_spconv_fwd, lt_spconv_plan_fwd*, and the ones inside
@@ -143,9 +148,8 @@ int64_t lt_conv_timer_end(float* ms, int32_t* meta, int64_t capacity);
 int64_t lt_bn_workspace_bytes(int64_t V, int32_t C);
 int lt_bn_stats(const float* x, int64_t V, int32_t C, void* ws, int64_t ws_bytes, float* mean, float* var,
                 lt_stream_t stream);
-/* mean / biased variance from the column sums of lt_spconv_plan_fwd_stats (nb = lt_spconv_stat_blocks) */
-int lt_bn_finalize_sums(const float* partial, int64_t nb, int64_t V, int32_t C, float* mean, float* var,
-                        lt_stream_t stream);
+/* mean / biased variance from the column sums lt_spconv_plan_fwd_stats left in stats_ws (V = Vout, C = Cout of that call) */
+int lt_bn_finalize_sums(void* stats_ws, int64_t V, int32_t C, float* mean, float* var, lt_stream_t stream);
 int lt_bn_apply(const float* x, const float* mean, const float* var, const float* gamma, const float* beta,
                 float eps, const float* residual, int32_t relu, float* y, int64_t V, int32_t C,
                 lt_stream_t stream);

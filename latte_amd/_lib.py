@@ -47,7 +47,8 @@ SIGNATURES = {
     "lt_conv_timer_begin": (ctypes.c_int, [I32]),
     "lt_conv_timer_end": (I64, [P, P, I64]),
     "lt_spconv_plan_fwd_stats": (ctypes.c_int, [P, P, P, P, I64, I64, I32, I32, I32, P, P]),
-    "lt_bn_finalize_sums": (ctypes.c_int, [P, I64, I64, I32, P, P, P]),
+    "lt_bn_finalize_sums": (ctypes.c_int, [P, I64, I32, P, P, P]),
+    "lt_spconv_stats_bytes": (I64, [I64, I32]),
     "lt_conv_bn_workspace_bytes": (I64, [I64, I32]),
     "lt_conv_bn_fwd": (ctypes.c_int, [P, P, P, I64, I64, I32, I32, I32, P, P, F32, P, I32, P, I64, P, P, P, P, P]),
     "lt_conv_bn_bwd": (ctypes.c_int, [P, P, P, P, P, P, F32, I32, I64, I32, P, I64, P, P, P, P, P, P, I64, I32, I32, P,

@@ -98,6 +98,26 @@ static inline LtPlanView lt_plan_view(void* mem, int K, int64_t V) {
   return v;
 }
 
+// Statistics workspace of lt_spconv_plan_fwd_stats / lt_bn_finalize_sums:
+// partial[nb][2][C] fp32 column sums per conv workgroup | stage[LT_STAT_SLICES][2][C] fp64 slice sums (nb > 2048)
+#define LT_STAT_SLICES 32
+struct LtStatsView {
+  float* partial;
+  double* stage;
+  int64_t bytes;
+};
+static inline LtStatsView lt_stats_view(void* mem, int64_t nb, int C) {
+  char* p = (char*)mem;
+  LtStatsView v;
+  int64_t off = 0;
+  v.partial = (float*)(p + off);
+  off += lt_align_up((nb > 0 ? nb : 1) * 2 * (int64_t)C * 4, 256);
+  v.stage = (double*)(p + off);
+  off += lt_align_up((int64_t)LT_STAT_SLICES * 2 * C * 8, 256);
+  v.bytes = off;
+  return v;
+}
+
 // ---- device helpers -------------------------------------------------------
 #define LT_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
 

@@ -5,8 +5,7 @@
 #include "../../include/latte_hip.h"
 
 extern "C" int64_t lt_conv_bn_workspace_bytes(int64_t Vout, int32_t Cout) {
-  const int64_t nb = lt_spconv_stat_blocks(Vout, Cout);
-  const int64_t a = lt_align_up((nb > 0 ? nb : 1) * 2 * (int64_t)Cout * 4, 256);
+  const int64_t a = lt_spconv_stats_bytes(Vout, Cout);
   const int64_t b = lt_bn_workspace_bytes(Vout, Cout);
   return (a > b ? a : b) + 2 * lt_align_up((int64_t)Cout * 4, 256) + 256;
 }
@@ -17,11 +16,9 @@ extern "C" int lt_conv_bn_fwd(const float* in, const float* packed, const void* 
                               float* mean, float* var, hipStream_t stream) {
   LT_REQUIRE(Vout >= 2, LT_ERR_ARG, "lt_conv_bn_fwd: batch statistics need more than one row (Vout=%lld)", (long long)Vout);
   LT_REQUIRE(ws && ws_bytes >= lt_conv_bn_workspace_bytes(Vout, Cout), LT_ERR_WORKSPACE, "lt_conv_bn_fwd: workspace too small");
-  float* partial = (float*)ws;
-  const int64_t nb = lt_spconv_stat_blocks(Vout, Cout);
-  int rc = lt_spconv_plan_fwd_stats(in, packed, plan, conv_out, Vin, Vout, Cin, Cout, K, partial, stream);
+  int rc = lt_spconv_plan_fwd_stats(in, packed, plan, conv_out, Vin, Vout, Cin, Cout, K, ws, stream);
   if (rc) return rc;
-  rc = lt_bn_finalize_sums(partial, nb, Vout, Cout, mean, var, stream);
+  rc = lt_bn_finalize_sums(ws, Vout, Cout, mean, var, stream);
   if (rc) return rc;
   return lt_bn_apply(conv_out, mean, var, gamma, beta, eps, residual, relu, y, Vout, Cout, stream);
 }

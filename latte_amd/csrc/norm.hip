@@ -135,30 +135,50 @@ __global__ __launch_bounds__(64) void k_sum_partials(const float* __restrict__ p
   }
 }
 
-// statistics from the per-workgroup column sums a conv wrote (lt_spconv_plan_fwd_stats): partial[b][0][c] = sum x,
-// partial[b][1][c] = sum x^2.  One 256-thread block per channel, fp64 accumulation in a fixed order.
-__global__ __launch_bounds__(256) void k_bn_finalize_sums(const float* __restrict__ partial, int64_t nb, int64_t V, int C,
-                                                          float* __restrict__ mean, float* __restrict__ var) {
-  __shared__ double s1s[256], s2s[256];
-  const int c = blockIdx.x, t = threadIdx.x;
+// mean / biased variance from the conv epilogue's per-workgroup column sums [nb][2][C].  Block (g, slice): 16 channels,
+// 64 row lanes, 64-B coalesced reads, fp64, fixed summation order.  FINAL: one slice, writes mean / var; otherwise the
+// slice sums go to stage[slice][2][C] (fp64) and a second pass over the slices finishes (nb > 2048 only).
+template <typename T, bool FINAL>
+__global__ __launch_bounds__(1024) void k_stats_reduce(const T* __restrict__ in, int64_t nb, int64_t V, int C,
+                                                       double* __restrict__ stage, float* __restrict__ mean,
+                                                       float* __restrict__ var) {
+  __shared__ double red[2][64][16];
+  const int t = threadIdx.x, cl = t & 15, rl = t >> 4;
+  const int g = blockIdx.x, sl = blockIdx.y, S = gridDim.y;
+  const int c = 16 * g + cl;
+  const int64_t per = (nb + S - 1) / S;
+  const int64_t b0 = sl * per, b1 = (b0 + per < nb) ? b0 + per : nb;
   double s1 = 0.0, s2 = 0.0;
-  for (int64_t b = t; b < nb; b += 256) {
-    s1 += (double)partial[b * 2 * C + c];
-    s2 += (double)partial[b * 2 * C + C + c];
+#pragma unroll 4
+  for (int64_t b = b0 + rl; b < b1; b += 64) {
+    s1 += (double)in[b * 2 * C + c];
+    s2 += (double)in[b * 2 * C + C + c];
   }
-  s1s[t] = s1;
-  s2s[t] = s2;
+  red[0][rl][cl] = s1;
+  red[1][rl][cl] = s2;
   __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
-    if (t < off) { s1s[t] += s1s[t + off]; s2s[t] += s2s[t + off]; }
-    __syncthreads();
+  // 2 x 16 sums of 64 values: 4 threads per sum, then a fixed-order add of the four
+  if (t < 128) {
+    const int which = t >> 6, part = (t >> 4) & 3;
+    double acc = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc += red[which][16 * part + i][cl];
+    red[which][16 * part][cl] = acc;
   }
-  if (t == 0) {
-    const double m = s1s[0] / (double)V;
-    double v = s2s[0] / (double)V - m * m;
-    if (v < 0.0) v = 0.0;
-    mean[c] = (float)m;
-    var[c] = (float)v;
+  __syncthreads();
+  if (t < 16) {
+    const double a1 = ((red[0][0][cl] + red[0][16][cl]) + red[0][32][cl]) + red[0][48][cl];
+    const double a2 = ((red[1][0][cl] + red[1][16][cl]) + red[1][32][cl]) + red[1][48][cl];
+    if (FINAL) {
+      const double m = a1 / (double)V;
+      double v = a2 / (double)V - m * m;
+      if (v < 0.0) v = 0.0;
+      mean[c] = (float)m;
+      var[c] = (float)v;
+    } else {
+      stage[((int64_t)sl * 2) * C + c] = a1;
+      stage[((int64_t)sl * 2 + 1) * C + c] = a2;
+    }
   }
 }
 
@@ -185,12 +205,22 @@ extern "C" int lt_bn_stats(const float* x, int64_t V, int32_t C, void* ws, int64
   return LT_OK;
 }
 
-extern "C" int lt_bn_finalize_sums(const float* partial, int64_t nb, int64_t V, int32_t C, float* mean, float* var,
-                                   hipStream_t stream) {
+extern "C" int lt_bn_finalize_sums(void* stats_ws, int64_t V, int32_t C, float* mean, float* var, hipStream_t stream) {
   int rc = check_vc("lt_bn_finalize_sums", V, C);
   if (rc) return rc;
-  LT_REQUIRE(partial && mean && var && nb >= 1, LT_ERR_ARG, "lt_bn_finalize_sums: bad args");
-  hipLaunchKernelGGL(k_bn_finalize_sums, dim3(C), dim3(256), 0, stream, partial, nb, V, C, mean, var);
+  LT_REQUIRE(C % 16 == 0, LT_ERR_ARG, "lt_bn_finalize_sums: C=%d must be a multiple of 16", C);
+  LT_REQUIRE(stats_ws && mean && var, LT_ERR_ARG, "lt_bn_finalize_sums: null pointer");
+  const int64_t nb = lt_spconv_stat_blocks(V, C);
+  LtStatsView sv = lt_stats_view(stats_ws, nb, C);
+  if (nb <= 2048) {
+    hipLaunchKernelGGL((k_stats_reduce<float, true>), dim3(C / 16, 1), dim3(1024), 0, stream, sv.partial, nb, V, C, sv.stage,
+                       mean, var);
+  } else {
+    hipLaunchKernelGGL((k_stats_reduce<float, false>), dim3(C / 16, LT_STAT_SLICES), dim3(1024), 0, stream, sv.partial, nb, V,
+                       C, sv.stage, mean, var);
+    hipLaunchKernelGGL((k_stats_reduce<double, true>), dim3(C / 16, 1), dim3(1024), 0, stream, sv.stage,
+                       (int64_t)LT_STAT_SLICES, V, C, sv.stage, mean, var);
+  }
   LT_LAUNCH_CHECK();
   return LT_OK;
 }

@@ -469,7 +469,13 @@ static int launch_plan(const PlanArgs& a, hipStream_t stream) {
 // coalesced 1-KiB load, the gathered A rows are 16 x 64-B pieces.  The next slab's operands are loaded into a second
 // register set while the current slab's MFMAs run; latency beyond that is covered by the other resident waves.
 // Summation order per output element is unchanged (k ascending, channel ascending) -> bitwise equal to the others.
-template <int SR, int NTW, int W>
+//
+// SK (split-k) flavour: the W waves own the same rows AND the same 16*NTW columns and share the slab list (wave w takes
+// slabs w, w+W, ...); their partial accumulators are added through LDS in wave order at the end.  Same parallelism as
+// W column groups, but a workgroup W times taller for the same chain length: 1/W of the weight traffic per flop, and
+// (SR+NTW)/(SR*NTW) operand loads per MFMA instead of (SR/W+NTW)/(SR/W*NTW).  Summation order differs from the table
+// kernel's single chain (W sub-chains, then a fixed-order sum): deterministic, but not bitwise equal to k_spconv_vec.
+template <int SR, int NTW, int W, bool SK = false>
 __global__ __launch_bounds__(64 * W) void k_spconv_rf(PlanArgs a) {
   constexpr int TPW = SR >= 4 ? SR / 4 : 1;    // plan tiles per workgroup
   constexpr int PARTS = SR >= 4 ? 1 : 4 / SR;  // workgroups per plan tile (SR < 4: a workgroup owns SR of its 4 strips)
@@ -479,6 +485,7 @@ __global__ __launch_bounds__(64 * W) void k_spconv_rf(PlanArgs a) {
   __shared__ int s_klist[LT_KMAX];
   __shared__ unsigned int s_act[LT_KMAX];  // per active offset: bit h = strip h has a neighbour
   __shared__ int s_nact;
+  __shared__ f32x4 s_red[SK ? W * NTW * 64 : 1];  // SK: [W][NTW][64] partial accumulators of one strip
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -488,7 +495,7 @@ __global__ __launch_bounds__(64 * W) void k_spconv_rf(PlanArgs a) {
   const int s0 = PARTS == 1 ? 0 : (int)(blockIdx.x % PARTS) * SR;  // first strip inside the plan tile
   const int64_t T = ((int64_t)a.Vout + LT_TM - 1) / LT_TM;
   const int J = a.Cin / 16, NTt = a.Cout / 16;
-  const int nt0 = (blockIdx.y * W + wave) * NTW;
+  const int nt0 = SK ? blockIdx.y * NTW : (blockIdx.y * W + wave) * NTW;
 
   if (wave == 0) {
     unsigned int act = 0u;
@@ -569,25 +576,97 @@ __global__ __launch_bounds__(64 * W) void k_spconv_rf(PlanArgs a) {
 
   f32x4 avA[SR], avB[SR], bA[NTW], bB[NTW];
   unsigned int vA = 0u, vB = 0u;
-  if (U > 0) {
+  // this wave's slabs: first, first + step, ... (all of them unless SK)
+  const int first = SK ? wave : 0, step = SK ? W : 1;
+  const int Uw = U > first ? (U - first + step - 1) / step : 0;
+  if (Uw > 0) {
     // slab u = (ki, j); slabs past the end are clamped to the last one and computed with an empty strip mask
-    int ki = 0, jj = 0;
+    int ki = 0, jj = first, pos = first;
+    while (jj >= J) { jj -= J; ++ki; }
     auto advance = [&]() {
-      if (ki * J + jj + 1 < U) {
-        if (++jj == J) { jj = 0; ++ki; }
+      if (pos + step < U) {
+        pos += step;
+        jj += step;
+#pragma unroll
+        for (int c = 0; c < step; ++c)
+          if (jj >= J) { jj -= J; ++ki; }
       }
     };
-    issue(0, 0, avA, bA, vA);
-    for (int u = 0; u < U; u += 2) {
+    issue(ki, jj, avA, bA, vA);
+    for (int u = 0; u < Uw; u += 2) {
       const unsigned int act0 = act_of(ki);
       advance();
       issue(ki, jj, avB, bB, vB);
       compute(act0, avA, bA, vA);
-      const unsigned int act1 = (u + 1 < U) ? act_of(ki) : 0u;
+      const unsigned int act1 = (u + 1 < Uw) ? act_of(ki) : 0u;
       advance();
       issue(ki, jj, avA, bA, vA);
       compute(act1, avB, bB, vB);
     }
+  }
+
+  if constexpr (SK) {
+    // strip h is finished by wave h % W: partial accumulators of the others through LDS, added in wave order; the
+    // finishing wave stores the rows and keeps their column sums
+    float s1[NTW], s2[NTW];
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) s1[n] = s2[n] = 0.f;
+#pragma unroll
+    for (int h = 0; h < SR; ++h) {
+      const int owner = h % W;
+      f32x4* red = s_red;
+      if (h > 0) __syncthreads();  // the previous strip's partials have been read
+      if (wave != owner) {
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) red[(wave * NTW + n) * 64 + lane] = acc[h][n];
+      }
+      __syncthreads();
+      if (wave == owner) {
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) {
+          f32x4 sum = owner == 0 ? acc[h][n] : red[n * 64 + lane];
+#pragma unroll
+          for (int w = 1; w < W; ++w) {
+            const f32x4 v = w == owner ? acc[h][n] : red[(w * NTW + n) * 64 + lane];
+            sum[0] += v[0]; sum[1] += v[1]; sum[2] += v[2]; sum[3] += v[3];
+          }
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) {
+            const int row = s_rows[16 * h + 4 * q + reg];
+            if (row >= 0) a.out[(int64_t)row * a.Cout + 16 * (nt0 + n) + r] = sum[reg];
+            s1[n] += sum[reg];
+            s2[n] += sum[reg] * sum[reg];
+          }
+        }
+      }
+    }
+    if (a.partial) {
+      // column sums of the workgroup's rows: per wave over its strips, then over the waves in wave order through LDS
+      float* redf = reinterpret_cast<float*>(s_red);  // [W][NTW][2][16]
+      __syncthreads();                                // the last strip's partial accumulators have been read
+#pragma unroll
+      for (int n = 0; n < NTW; ++n) {
+        float t1 = s1[n], t2 = s2[n];
+        t1 += __shfl_xor(t1, 16, 64); t2 += __shfl_xor(t2, 16, 64);
+        t1 += __shfl_xor(t1, 32, 64); t2 += __shfl_xor(t2, 32, 64);
+        if (q == 0) {
+          redf[((wave * NTW + n) * 2 + 0) * 16 + r] = t1;
+          redf[((wave * NTW + n) * 2 + 1) * 16 + r] = t2;
+        }
+      }
+      __syncthreads();
+      if (wave == 0 && lane < 32) {
+        const int which = lane >> 4;
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) {
+          float t = 0.f;
+#pragma unroll
+          for (int w = 0; w < W; ++w) t += redf[((w * NTW + n) * 2 + which) * 16 + r];
+          a.partial[((int64_t)blockIdx.x * 2 + which) * a.Cout + 16 * (nt0 + n) + r] = t;
+        }
+      }
+    }
+    return;
   }
 
 #pragma unroll
@@ -637,6 +716,42 @@ static void launch_rf_one(const PlanArgs& a, int gy, hipStream_t stream) {
     gx = (unsigned)(((a.Vout + LT_TM - 1) / LT_TM) * (4 / SR));
   }
   hipLaunchKernelGGL((k_spconv_rf<SR, NTW, W>), dim3(gx, (unsigned)gy), dim3(64 * W), 0, stream, a);
+}
+
+template <int SR, int NTW, int W>
+static void launch_sk_one(const PlanArgs& a, hipStream_t stream) {
+  unsigned gx;
+  if (SR >= 4) gx = (unsigned)((a.Vout + 16 * SR - 1) / (16 * SR));
+  else gx = (unsigned)(((a.Vout + LT_TM - 1) / LT_TM) * (4 / SR));
+  hipLaunchKernelGGL((k_spconv_rf<SR, NTW, W, true>), dim3(gx, (unsigned)(a.Cout / (16 * NTW))), dim3(64 * W), 0, stream, a);
+}
+
+// split-k launch: sr in {1,2,4}, ntw in {1,2,3,4,6,8}, w in {2,4,8}
+static int launch_sk(const PlanArgs& a, int sr, int ntw, int w, hipStream_t stream) {
+#define LT_SK_W(SRv, NTWv)                                          \
+  do {                                                              \
+    if (w == 8) launch_sk_one<SRv, NTWv, 8>(a, stream);             \
+    else if (w == 4) launch_sk_one<SRv, NTWv, 4>(a, stream);        \
+    else launch_sk_one<SRv, NTWv, 2>(a, stream);                    \
+  } while (0)
+#define LT_SK_NTW(SRv)                                              \
+  do {                                                              \
+    switch (ntw) {                                                  \
+      case 8: LT_SK_W(SRv, 8); break;                               \
+      case 6: LT_SK_W(SRv, 6); break;                               \
+      case 4: LT_SK_W(SRv, 4); break;                               \
+      case 3: LT_SK_W(SRv, 3); break;                               \
+      case 2: LT_SK_W(SRv, 2); break;                               \
+      default: LT_SK_W(SRv, 1); break;                              \
+    }                                                               \
+  } while (0)
+  if (sr == 4) LT_SK_NTW(4);
+  else if (sr == 2) LT_SK_NTW(2);
+  else LT_SK_NTW(1);
+#undef LT_SK_NTW
+#undef LT_SK_W
+  LT_LAUNCH_CHECK();
+  return LT_OK;
 }
 
 template <int NTW>
@@ -722,17 +837,21 @@ extern "C" int64_t lt_conv_timer_end(float* ms, int32_t* meta, int64_t capacity)
   return n;
 }
 
-// default kernel shape: 2 column tiles per wave; the tallest workgroup (64, 32 or 16 rows) that still puts >= 10 000
-// waves on the chip -- a wave's slab chain is sequential, so coarse levels need short chains more than weight reuse
-// (measured on every level/width of the U-Net: tools/conv_bench.py)
-static void rf_default_shape(int64_t Vout, int Cout, int* sr, int* ntw) {
+// Default kernel shape (measured on every level / width of the U-Net, tools/conv_bench.py + tools/cb_sk.sh):
+// the split-k flavour with 4 column tiles per wave (3 for Cout = 48, 96, ...), 32-row workgroups of 4 waves (64 rows
+// when the wave has 3 tiles); 16-row workgroups of 8 waves when that leaves fewer than 4000 waves (coarsest level).
+struct LtConvShape {
+  int sr, ntw, w;
+};
+static LtConvShape conv_default_shape(int64_t Vout, int Cout) {
   const int ntt = Cout / 16;
-  *ntw = ntt % 2 == 0 ? 2 : 1;
-  *sr = 1;
-  for (int c = 4; c >= 1; c >>= 1) {
-    const int64_t waves = ((Vout + 16 * c - 1) / (16 * c)) * (ntt / *ntw);
-    if (waves >= 10000) { *sr = c; break; }
-  }
+  LtConvShape s;
+  s.ntw = ntt % 4 == 0 ? 4 : ntt % 3 == 0 ? 3 : ntt % 2 == 0 ? 2 : 1;
+  s.sr = s.ntw == 3 ? 4 : 2;
+  s.w = 4;
+  const int64_t waves = ((Vout + 16 * s.sr - 1) / (16 * s.sr)) * (ntt / s.ntw) * s.w;
+  if (waves < 4000) { s.sr = 1; s.w = 8; }
+  return s;
 }
 static int64_t rf_grid_x(int64_t Vout, int sr) {
   if (sr >= 4) return (Vout + 16 * sr - 1) / (16 * sr);
@@ -740,10 +859,14 @@ static int64_t rf_grid_x(int64_t Vout, int sr) {
 }
 
 extern "C" int64_t lt_spconv_stat_blocks(int64_t Vout, int32_t Cout) {
-  int sr, ntw;
   if (Vout <= 0 || Cout < 16) return 0;
-  rf_default_shape(Vout, Cout, &sr, &ntw);
-  return rf_grid_x(Vout, sr);
+  const LtConvShape s = conv_default_shape(Vout, Cout);
+  return rf_grid_x(Vout, s.sr);
+}
+
+extern "C" int64_t lt_spconv_stats_bytes(int64_t Vout, int32_t Cout) {
+  if (Cout < 16) return 256;
+  return lt_stats_view(nullptr, lt_spconv_stat_blocks(Vout, Cout), Cout).bytes;
 }
 
 static int spconv_plan_impl(const float* in, const float* packed, const void* plan, float* out, int64_t Vin,
@@ -757,10 +880,10 @@ extern "C" int lt_spconv_plan_fwd_v(const float* in, const float* packed, const 
 }
 
 extern "C" int lt_spconv_plan_fwd_stats(const float* in, const float* packed, const void* plan, float* out, int64_t Vin,
-                                        int64_t Vout, int32_t Cin, int32_t Cout, int32_t K, float* partial,
+                                        int64_t Vout, int32_t Cin, int32_t Cout, int32_t K, void* stats_ws,
                                         hipStream_t stream) {
-  LT_REQUIRE(partial, LT_ERR_ARG, "lt_spconv_plan_fwd_stats: partial is null");
-  return spconv_plan_impl(in, packed, plan, out, Vin, Vout, Cin, Cout, K, 0, partial, stream);
+  LT_REQUIRE(stats_ws, LT_ERR_ARG, "lt_spconv_plan_fwd_stats: stats_ws is null");
+  return spconv_plan_impl(in, packed, plan, out, Vin, Vout, Cin, Cout, K, 0, (float*)stats_ws, stream);
 }
 
 static int spconv_plan_impl(const float* in, const float* packed, const void* plan, float* out, int64_t Vin,
@@ -777,9 +900,12 @@ static int spconv_plan_impl(const float* in, const float* packed, const void* pl
   PlanArgs a{in, packed, pv.tnbr, pv.tmask, pv.order, pv.torder, out, (int)Vin, (int)Vout, Cin, Cout, K, partial};
   LtConvTimerScope timed(stream, Cin, Cout, K, Vout);
   const int ntt = Cout / 16;
-  int sr, ntw;
-  rf_default_shape(Vout, Cout, &sr, &ntw);
   LT_REQUIRE(!(partial && variant != 0), LT_ERR_ARG, "lt_spconv_plan_fwd: statistics need the default variant");
+  if (variant == 0) {
+    const LtConvShape sh = conv_default_shape(Vout, Cout);
+    return launch_sk(a, sh.sr, sh.ntw, sh.w, stream);
+  }
+  int sr = 1, ntw = 1;
   if (variant == 1) {  // the LDS-DMA staged kernel
     if (ntt % 8 == 0) return launch_plan<8, 2>(a, stream);
     if (ntt % 6 == 0) return launch_plan<6, 2>(a, stream);
@@ -788,7 +914,18 @@ static int spconv_plan_impl(const float* in, const float* packed, const void* pl
     if (ntt % 2 == 0) return launch_plan<2, 8>(a, stream);
     return launch_plan<1, 8>(a, stream);
   }
-  if (variant >= 100) {
+  if (variant >= 1000) {  // split-k: 1000 + 100*SR + 10*NTW + W
+    const int v = variant - 1000;
+    sr = v / 100;
+    ntw = (v / 10) % 10;
+    const int w = v % 10;
+    LT_REQUIRE((sr == 1 || sr == 2 || sr == 4) && (ntw == 1 || ntw == 2 || ntw == 3 || ntw == 4 || ntw == 6 || ntw == 8) &&
+                   (w == 2 || w == 4 || w == 8) && ntt % ntw == 0,
+               LT_ERR_ARG, "lt_spconv_plan_fwd_v: bad variant %d for Cout=%d", variant, Cout);
+    return launch_sk(a, sr, ntw, w, stream);
+  }
+  LT_REQUIRE(variant >= 100, LT_ERR_ARG, "lt_spconv_plan_fwd_v: unknown variant %d", variant);
+  {
     sr = variant / 100;
     ntw = variant % 100;
     LT_REQUIRE((sr == 1 || sr == 2 || sr == 4 || sr == 8) && (ntw == 1 || ntw == 2 || ntw == 4) && ntt % ntw == 0, LT_ERR_ARG,

@@ -110,17 +110,18 @@ class HR_Block(nn.Module):
                 segs.append((i, j, int(h_start[j]), h_sizes[j]))
         return segs, h_start, h_sizes
 
-    def forward(self, anchor_batch: Dict, anchor_type: str, hist_batch: Dict, hist_type: str) -> Dict:
-        required = ["seg_logit", "pose", "scene_name", "scan_ID", "ori_points"]
+    def geometry(self, anchor_batch: Dict, anchor_type: str, hist_batch: Dict, hist_type: str, device=None) -> Dict:
+        """Everything of the block that depends on points and poses only (no logits): ST-voxel keys, the sort, voxel
+        segments and the anchor/hist correspondence.  All host synchronisations of the block are in here, so a caller
+        can run it on a side stream while the networks that produce the logits are still executing."""
+        required = ["pose", "scene_name", "scan_ID", "ori_points"]
         assert set(required) <= set(anchor_batch.keys())
         assert set(required) <= set(hist_batch.keys())
         assert anchor_type.upper() in ["2D", "3D"] and hist_type.upper() in ["2D", "3D"]
         ac_ref = "img_indices" if anchor_type.upper() == "2D" else "ori_points"
         hs_ref = "img_indices" if hist_type.upper() == "2D" else "ori_points"
-        a_logits, h_logits = anchor_batch["seg_logit"], hist_batch["seg_logit"]
-        dev = a_logits.device
+        dev = device if device is not None else anchor_batch["ori_points"][0].device
         B = len(anchor_batch["pose"])
-        C = a_logits.shape[1]
         segs, h_start, h_sizes = self._plan(anchor_batch, ac_ref, hist_batch, hs_ref)
         a_sizes = [int(anchor_batch[ac_ref][i].shape[0]) for i in range(B)]
         for i in range(B):
@@ -132,8 +133,6 @@ class HR_Block(nn.Module):
         h_pts = torch.cat([p.reshape(-1, 3) for p in hist_batch["ori_points"]], 0).to(dev, torch.float32)
         a_pts = torch.cat([p.reshape(-1, 3) for p in anchor_batch["ori_points"]], 0).to(dev, torch.float32)
         Ph, Pa = h_pts.shape[0], a_pts.shape[0]
-        assert h_logits.shape[0] == Ph and a_logits.shape[0] == Pa
-        S = len(segs)
         seg_n = np.array([s[3] for s in segs], dtype=np.int64)
         seg_out = np.concatenate([[0], np.cumsum(seg_n)]).astype(np.int64)
         E = int(seg_out[-1])
@@ -164,18 +163,6 @@ class HR_Block(nn.Module):
                                 self.max_range, self.voxel_size, self.min_offset)
         h_selem, h_inv, h_uk, h_seg = ops.sort_segments(h_keys)
         a_selem, a_inv, a_uk, a_seg = ops.sort_segments(a_keys)
-        Vt, Va = h_uk.numel(), a_uk.numel()
-
-        # ---- per-voxel means
-        h_probs, h_ety = ops.softmax_entropy(h_logits.detach().float().contiguous())
-        tr_voxel_probs = ops.segment_reduce(h_probs, h_selem, h_seg, "mean", src_index=h_src)
-        tr_voxel_ety = ops.segment_reduce(h_ety, h_selem, h_seg, "mean", src_index=h_src)
-        a_in = a_logits if a_logits.dtype == torch.float32 else a_logits.float()
-        ac_voxel_probs = _VoxelMeanSoftmax.apply(a_in.contiguous(), a_selem, a_inv, a_seg)
-
-        # ---- ST-voxel entropy written back to the hist points (mean over the anchors that see the point)
-        hs_pc_ety = ops.st_gather_back(tr_voxel_ety, h_inv, d(h_start, torch.int64), d(frame_seg, torch.int32),
-                                       seg_out_d, Ph)
 
         # ---- correspondence
         a_sel, t_sel = ops.st_join(a_uk, h_uk)
@@ -187,7 +174,34 @@ class HR_Block(nn.Module):
             raise AssertionError
         ac_first = a_selem[a_seg[:-1].long()].long()            # first in-range point of each anchor voxel
         tr_first = h_src[h_selem[h_seg[:-1].long()].long()].long()  # ... of each hist voxel, as hist point index
-        vox = _decode_xyz(matched_keys)
+        return dict(Ph=Ph, Pa=Pa, B=B, h_src=h_src, h_selem=h_selem, h_inv=h_inv, h_seg=h_seg, a_selem=a_selem,
+                    a_inv=a_inv, a_seg=a_seg, a_sel_l=a_sel_l, t_sel_l=t_sel_l, per_anchor=per_anchor,
+                    vox=_decode_xyz(matched_keys), ac_p2v=ac_first[a_sel_l], tr_p2v=tr_first[t_sel_l],
+                    h_start_d=d(h_start, torch.int64), frame_seg_d=d(frame_seg, torch.int32), seg_out_d=seg_out_d)
+
+    def forward(self, anchor_batch: Dict, anchor_type: str, hist_batch: Dict, hist_type: str, geo: Dict = None) -> Dict:
+        assert "seg_logit" in anchor_batch and "seg_logit" in hist_batch
+        a_logits, h_logits = anchor_batch["seg_logit"], hist_batch["seg_logit"]
+        dev = a_logits.device
+        C = a_logits.shape[1]
+        if geo is None:
+            geo = self.geometry(anchor_batch, anchor_type, hist_batch, hist_type, device=dev)
+        Ph, Pa = geo["Ph"], geo["Pa"]
+        assert h_logits.shape[0] == Ph and a_logits.shape[0] == Pa
+        h_src, h_selem, h_seg = geo["h_src"], geo["h_selem"], geo["h_seg"]
+        a_sel_l, t_sel_l, per_anchor = geo["a_sel_l"], geo["t_sel_l"], geo["per_anchor"]
+
+        # ---- per-voxel means
+        h_probs, h_ety = ops.softmax_entropy(h_logits.detach().float().contiguous())
+        tr_voxel_probs = ops.segment_reduce(h_probs, h_selem, h_seg, "mean", src_index=h_src)
+        tr_voxel_ety = ops.segment_reduce(h_ety, h_selem, h_seg, "mean", src_index=h_src)
+        a_in = a_logits if a_logits.dtype == torch.float32 else a_logits.float()
+        ac_voxel_probs = _VoxelMeanSoftmax.apply(a_in.contiguous(), geo["a_selem"], geo["a_inv"], geo["a_seg"])
+
+        # ---- ST-voxel entropy written back to the hist points (mean over the anchors that see the point)
+        hs_pc_ety = ops.st_gather_back(tr_voxel_ety, geo["h_inv"], geo["h_start_d"], geo["frame_seg_d"], geo["seg_out_d"], Ph)
+
+        vox = geo["vox"]
         split = lambda t: list(torch.split(t, per_anchor, 0))
         tr_logits_all = tr_voxel_probs[t_sel_l]
         out = {
@@ -198,14 +212,14 @@ class HR_Block(nn.Module):
             "tr_ety_loss": [],
             "tr_pc2img_mask": [],
             "tr_img_points": [],
-            "ac_p2v_indices": split(ac_first[a_sel_l]),
-            "tr_p2v_indices": split(tr_first[t_sel_l]),
+            "ac_p2v_indices": split(geo["ac_p2v"]),
+            "tr_p2v_indices": split(geo["tr_p2v"]),
             "hs_pc_ety": hs_pc_ety,
         }
         if self.conf_perc is not None and self.conf_perc > 0.0:
             out["tr_conf_mask"] = refine_ety(tr_voxel_ety, tr_logits_all.argmax(1), self.conf_perc, num_classes=C)
         else:
-            out["tr_conf_mask"] = torch.ones(t_sel.numel(), dtype=torch.bool, device=dev)
+            out["tr_conf_mask"] = torch.ones(t_sel_l.numel(), dtype=torch.bool, device=dev)
         return out
 
 

@@ -112,7 +112,7 @@ def shard_scan_offset(rank: int, scans_per_rank: int) -> int:
 class LatteStep:
     def __init__(self, model_3d: nn.Module, num_classes: int, hr_cfg: Dict, lr: float = 1e-3, conf_perc=None,
                  lambda_hr_23: float = 0.3, lambda_hr_32: float = 0.3, lambda_ety_ps: float = 1.0, class_weights=None,
-                 process_group=None, overlap: bool = True):
+                 process_group=None, overlap: bool = False, hr_side_stream: bool = True):
         self.model = configure_model_norm(model_3d, reset_dropout=True)
         self.ema_model = create_ema_model(self.model)
         self.hr = HR_Block(**hr_cfg)
@@ -128,6 +128,10 @@ class LatteStep:
         self.timers = None
         self.overlap = overlap      # teacher and student forward on two streams (same results, see forward_backward)
         self._streams = None
+        # HR_Block.geometry (points and poses only, all of the block's host syncs) on a side stream while the two
+        # forward passes execute on the main stream
+        self.hr_side_stream = hr_side_stream
+        self._side = None
 
     # -------------------------------------------------------------------------------------------------
     def _tick(self, name: str):
@@ -150,6 +154,15 @@ class LatteStep:
         pc2img = batch["pc2img_idx"]
         ema_logit_2d = batch["logit_2d_teacher"]
         preds_2d = {"seg_logit": batch["logit_2d_student"]}
+        ori_2d = [p[m] for p, m in zip(batch["ori_points"], pc2img)]
+        main = torch.cuda.current_stream()
+        side = None
+        if self.hr_side_stream and self.timers is None:
+            if self._side is None:
+                self._side = torch.cuda.Stream()
+            side = self._side
+            ev_in = torch.cuda.Event()
+            ev_in.record(main)   # inputs of the geometry are ready; earlier steps' work on `main` is before this point
         if self.overlap and self.timers is None:
             # index structures once, then teacher and student forward side by side on two HIP streams: the two passes
             # are independent, and most of their kernels (BN, point<->voxel, coarse-level convs) are far too small to
@@ -183,13 +196,25 @@ class LatteStep:
             preds_3d["seg_logit"] = inverse_to_all(preds_3d["seg_logit"], batch)
             self._tick("student_fwd")
 
-        ori_2d = [p[m] for p, m in zip(batch["ori_points"], pc2img)]
         a2 = dict(preds_2d, ori_points=ori_2d, **extra)
         h2 = dict(seg_logit=ema_logit_2d, ori_points=ori_2d, **extra)
         a3 = dict(seg_logit=preds_3d["seg_logit"], ori_points=batch["ori_points"], **extra)
         h3 = dict(seg_logit=ema3d["seg_logit"], ori_points=batch["ori_points"], **extra)
-        hr23 = self.hr(a2, "2D", h3, "3D")
-        hr32 = self.hr(a3, "3D", h2, "2D")
+        geo23 = geo32 = None
+        if side is not None:
+            # the forwards above are queued on the main stream; the sync-heavy geometry of both HR calls runs beside
+            # them (its inputs were ready at ev_in)
+            side.wait_event(ev_in)
+            with torch.cuda.stream(side):
+                geo23 = self.hr.geometry(a2, "2D", h3, "3D")
+                geo32 = self.hr.geometry(a3, "3D", h2, "2D")
+            main.wait_stream(side)
+            for geo in (geo23, geo32):
+                for t in geo.values():
+                    if torch.is_tensor(t):
+                        t.record_stream(main)
+        hr23 = self.hr(a2, "2D", h3, "3D", geo=geo23)
+        hr32 = self.hr(a3, "3D", h2, "2D", geo=geo32)
         self._tick("hr_x2")
 
         # ---- pseudo labels (latte.py:207-238)

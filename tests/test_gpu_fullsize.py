@@ -56,8 +56,11 @@ def test_kernel_map_symmetry_and_plan_conv_bitwise(big):
     feats = torch.randn(V, 96, generator=g).cuda()
     pw = ops.pack_weights((torch.randn(27, 96, 96, generator=g) / 50).cuda(), 0)
     a = ops.spconv(feats, pw, res, 96)
-    b = ops.spconv_plan(feats, pw, kmap.plan(), 27, V, 96)
+    b = ops.spconv_plan(feats, pw, kmap.plan(), 27, V, 96, variant=202)   # single-chain variant: bit for bit
     assert torch.equal(a, b)
+    b = ops.spconv_plan(feats, pw, kmap.plan(), 27, V, 96)                # default (split-k): re-associated sum
+    assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max())
+    assert torch.equal(b, ops.spconv_plan(feats, pw, kmap.plan(), 27, V, 96))   # and reproducible
     # linearity (fp32 tolerance): conv(x + y) = conv(x) + conv(y)
     f2 = torch.randn(V, 96, generator=g).cuda()
     lhs = ops.spconv_plan(feats + f2, pw, kmap.plan(), 27, V, 96)

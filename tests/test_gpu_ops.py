@@ -175,12 +175,19 @@ def test_kmap_order_is_stable_mask_sort(scans_small, ks, stride):
     assert torch.equal(ops.spconv(feats, pw, resd, 32), ops.spconv(feats, pw, resd, 32, order=ops.kmap_order(resd)))
 
 
+def _sk_variants(cout):
+    """split-k variant codes 1000 + 100*SR + 10*NTW + W valid for this width"""
+    return [1000 + 100 * sr + 10 * ntw + w for sr in (1, 2, 4) for ntw in (1, 2, 3, 4, 6, 8) for w in (2, 4, 8)
+            if (cout // 16) % ntw == 0]
+
+
 @pytest.mark.parametrize("cin,cout", [(16, 16), (32, 32), (32, 64), (96, 96), (128, 96), (192, 128), (384, 256), (48, 48),
                                       (64, 80)])
 @pytest.mark.parametrize("ks,stride", [(3, 1), (2, 2)])
 def test_spconv_plan_is_bitwise_equal_to_table_kernel(scans_small, cin, cout, ks, stride):
-    """the planned (mask-sorted, LDS-DMA pipelined) kernel must reproduce the plain table kernel bit for bit, on the
-    forward table and on the reverse table (transposed conv / strided backward)"""
+    """the planned kernels against the plain table kernel, on the forward table and on the reverse table (transposed conv
+    / strided backward): single-chain variants (LDS-DMA staged, register-fed) bit for bit; split-k variants (and the
+    default, which is one) to fp32 rounding of the re-associated sum, and bit for bit from run to run"""
     from latte_amd import ops
     c = scans_small["coords"]
     _, _, out_coords, res = ts_ref.build_kmap(c, 1, ks, stride)
@@ -192,18 +199,25 @@ def test_spconv_plan_is_bitwise_equal_to_table_kernel(scans_small, cin, cout, ks
     pw = ops.pack_weights(w, 0)
     a = ops.spconv(feats, pw, resd, cout)
     plan = ops.kmap_plan(resd)
-    variants = [0, 1] + [100 * sr + ntw for sr in (1, 2, 4, 8) for ntw in (1, 2, 4) if (cout // 16) % ntw == 0]
+    variants = [1] + [100 * sr + ntw for sr in (1, 2, 4, 8) for ntw in (1, 2, 4) if (cout // 16) % ntw == 0]
     for v in variants:
         b = ops.spconv_plan(feats, pw, plan, K, resd.shape[1], cout, variant=v)
         assert torch.equal(a, b), v
+    for v in [0] + _sk_variants(cout):
+        b = ops.spconv_plan(feats, pw, plan, K, resd.shape[1], cout, variant=v)
+        assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max()), v
+        assert torch.equal(b, ops.spconv_plan(feats, pw, plan, K, resd.shape[1], cout, variant=v)), v
     rev = ops.kmap_reverse(resd, c.shape[0])
     gout = torch.randn(out_coords.shape[0], cout, generator=g).cuda()
     pwt = ops.pack_weights(w, 1)
     a = ops.spconv(gout, pwt, rev, cin)
     rplan = ops.kmap_plan(rev)
-    for v in [0, 1] + [100 * sr + ntw for sr in (1, 2, 4, 8) for ntw in (1, 2, 4) if (cin // 16) % ntw == 0]:
+    for v in [1] + [100 * sr + ntw for sr in (1, 2, 4, 8) for ntw in (1, 2, 4) if (cin // 16) % ntw == 0]:
         b = ops.spconv_plan(gout, pwt, rplan, K, c.shape[0], cin, variant=v)
         assert torch.equal(a, b), v
+    for v in [0] + _sk_variants(cin):
+        b = ops.spconv_plan(gout, pwt, rplan, K, c.shape[0], cin, variant=v)
+        assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max()), v
 
 
 def test_spconv_plan_empty_rows_and_ragged_tail():
@@ -220,9 +234,13 @@ def test_spconv_plan_empty_rows_and_ragged_tail():
     nd = nbr.cuda()
     a = ops.spconv(feats, pw, nd, C)
     plan = ops.kmap_plan(nd)
-    for v in (0, 1, 101, 102, 201, 202, 401, 402, 801, 802):
+    for v in (1, 101, 102, 201, 202, 401, 402, 801, 802):
         b = ops.spconv_plan(feats, pw, plan, K, V, C, variant=v)
         assert torch.equal(a, b), v
+        assert float(b[5].abs().max()) == 0.0
+    for v in [0] + _sk_variants(C):
+        b = ops.spconv_plan(feats, pw, plan, K, V, C, variant=v)
+        assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max()), v
         assert float(b[5].abs().max()) == 0.0
 
 
@@ -314,7 +332,7 @@ def test_conv_bn_composite_matches_unfused_ops(scans_small, cin, cout, ks, strid
     plan = kmap.reverse_plan() if transposed else kmap.plan()
     conv_o, y_o, mean, var = ops.conv_bn_fwd(x.detach(), ops.pack_weights(w, 0), plan, K, n_out, cout, gamma.detach(),
                                              beta.detach(), eps, None, False)
-    assert torch.equal(conv_o, conv_u)
+    assert torch.equal(conv_o, conv_u)  # same default kernel with and without the statistics epilogue
     c64 = conv_u.double()
     assert torch.allclose(mean.double(), c64.mean(0), rtol=1e-5, atol=1e-6)
     assert torch.allclose(var.double(), c64.var(0, unbiased=False), rtol=1e-4, atol=1e-7)

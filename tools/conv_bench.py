@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--full360", action="store_true", default=True)
     ap.add_argument("--out", default=None)
     ap.add_argument("--variant", type=int, default=0, help="lt_spconv_plan_fwd_v variant (with --order plan)")
+    ap.add_argument("--variants", default=None, help="comma list of variants to sweep (with --order plan); each is checked "
+                    "against variant 0")
     args = ap.parse_args()
 
     import torch
@@ -99,29 +101,41 @@ def main():
         act = (torch.cat([nb, pad], 1).view(K, -1, 16) >= 0).any(2).sum().item()
         print(f"order={args.order}: issued row-offsets {act * 16} vs pairs {M} -> MFMA utilisation {M / (act * 16):.3f}")
     rows = []
+    variants = [args.variant] if args.variants is None else [int(v) for v in args.variants.split(",")]
+
+    def ntw_of(variant):
+        return (variant // 10) % 10 if variant >= 1000 else variant % 100
+
     for C in [int(v) for v in args.channels.split(",")]:
         feats = torch.randn(V, C, device=dev)
         w = torch.randn(27, C, C, device=dev) * 0.05
         packed = ops.pack_weights(w, 0)
-        if plan is not None:
-            run = lambda: ops.spconv_plan(feats, packed, plan, 27, V, C)
-        else:
-            run = lambda: ops.spconv(feats, packed, nbr, C, order=order)
-        for _ in range(2):
-            out = run()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(args.reps):
-            out = run()
-        e1.record()
-        torch.cuda.synchronize()
-        us = 1e3 * e0.elapsed_time(e1) / args.reps
-        flops = 2.0 * M * C * C
-        comp_bytes = 4.0 * (V * C * 2 + 27 * C * C) + 4.0 * 27 * V
-        rows.append(dict(variant=args.variant, C=C, V=V, M=M, pairs_per_voxel=round(M / V, 2), us=round(us, 1),
-                         tflops=round(flops / us / 1e6, 2), frac_f32_mfma=round(flops / us / 1e6 / 157.3, 4),
-                         compulsory_GBs=round(comp_bytes / us / 1e3, 1), gathered_GBs=round(4.0 * M * C / us / 1e3, 1)))
-        print(json.dumps(rows[-1]), flush=True)
+        ref = ops.spconv_plan(feats, packed, plan, 27, V, C, variant=0) if plan is not None else None
+        for variant in variants:
+            if plan is not None:
+                if variant >= 100 and (C // 16) % ntw_of(variant) != 0:
+                    continue
+                run = lambda: ops.spconv_plan(feats, packed, plan, 27, V, C, variant=variant)
+                err = float((run() - ref).abs().max() / ref.abs().max())
+                assert err < 1e-5, (variant, C, err)
+            else:
+                run = lambda: ops.spconv(feats, packed, nbr, C, order=order)
+            for _ in range(2):
+                out = run()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.reps):
+                out = run()
+            e1.record()
+            torch.cuda.synchronize()
+            us = 1e3 * e0.elapsed_time(e1) / args.reps
+            flops = 2.0 * M * C * C
+            comp_bytes = 4.0 * (V * C * 2 + 27 * C * C) + 4.0 * 27 * V
+            rows.append(dict(variant=variant, stride=args.stride, C=C, V=V, M=M, pairs_per_voxel=round(M / V, 2),
+                             us=round(us, 1), tflops=round(flops / us / 1e6, 2),
+                             frac_f32_mfma=round(flops / us / 1e6 / 157.3, 4),
+                             compulsory_GBs=round(comp_bytes / us / 1e3, 1), gathered_GBs=round(4.0 * M * C / us / 1e3, 1)))
+            print(json.dumps(rows[-1]), flush=True)
     if args.out:
         json.dump(dict(args=vars(args), rows=rows), open(args.out, "w"), indent=1)
 
