@@ -42,8 +42,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scans", type=int, default=3, help="scans in the CPU-oracle sample")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not time the conv launches with HIP events")
-    ap.add_argument("--overlap", action="store_true", help="teacher and student forward on two HIP streams (no measured "
-                    "gain: the step is host-bound; per-kernel event times then include the other stream's kernels)")
+    ap.add_argument("--no-side-stream", action="store_true", help="run the input-only, sync-heavy work (index structures, "
+                    "HR geometry) on the main stream too")
     ap.add_argument("--dump-conv", default=None, help="write the per-launch conv table of one step (JSON) here")
     ap.add_argument("--fwd-only", action="store_true", help="time teacher forward only (BASELINE config 5 style)")
     return ap.parse_args()
@@ -109,7 +109,7 @@ def main():
     w = synth.workload(args.workload)
     torch.manual_seed(1)  # cfg.RNG_SEED (latte/common/config/base.py:173); same weights on every rank
     model = Net3DSeg(w["C"], True, "SPVCNN", {"cr": args.cr}).to(dev)
-    step = LatteStep(model, w["C"], hr_cfg_of(w), process_group=pg, overlap=args.overlap)
+    step = LatteStep(model, w["C"], hr_cfg_of(w), process_group=pg, side_stream=not args.no_side_stream)
     batch = build_batch(w, device=dev, scan_offset=shard_scan_offset(rank, w["B"]), seed=rank)
     n_points = batch["n_points"]
 

@@ -76,6 +76,11 @@ def _decode_xyz(keys: torch.Tensor) -> torch.Tensor:
     return torch.stack([(keys >> 32) & 0xFFFF, (keys >> 16) & 0xFFFF, keys & 0xFFFF], 1).to(torch.int32)
 
 
+class _HRResult(dict):
+    """HR_Block's output dict (the reference's 11 keys) plus, as an attribute, the anchor index of every matched row"""
+    row_anchor = None
+
+
 class HR_Block(nn.Module):
     def __init__(self, temp_wd_size: int = 50, max_range: int = 50, voxel_size: float = 0.2, conf_perc: float = 0.75,
                  exclude_labels: Tuple[int] = None, resize: Tuple[int, int] = None):
@@ -177,6 +182,7 @@ class HR_Block(nn.Module):
         return dict(Ph=Ph, Pa=Pa, B=B, h_src=h_src, h_selem=h_selem, h_inv=h_inv, h_seg=h_seg, a_selem=a_selem,
                     a_inv=a_inv, a_seg=a_seg, a_sel_l=a_sel_l, t_sel_l=t_sel_l, per_anchor=per_anchor,
                     vox=_decode_xyz(matched_keys), ac_p2v=ac_first[a_sel_l], tr_p2v=tr_first[t_sel_l],
+                    row_anchor=(matched_keys >> 48),
                     h_start_d=d(h_start, torch.int64), frame_seg_d=d(frame_seg, torch.int32), seg_out_d=seg_out_d)
 
     def forward(self, anchor_batch: Dict, anchor_type: str, hist_batch: Dict, hist_type: str, geo: Dict = None) -> Dict:
@@ -204,7 +210,7 @@ class HR_Block(nn.Module):
         vox = geo["vox"]
         split = lambda t: list(torch.split(t, per_anchor, 0))
         tr_logits_all = tr_voxel_probs[t_sel_l]
-        out = {
+        out = _HRResult({
             "ac_logits": split(ac_voxel_probs[a_sel_l]),
             "ac_voxels": split(vox),
             "tr_logits": split(tr_logits_all),
@@ -215,7 +221,8 @@ class HR_Block(nn.Module):
             "ac_p2v_indices": split(geo["ac_p2v"]),
             "tr_p2v_indices": split(geo["tr_p2v"]),
             "hs_pc_ety": hs_pc_ety,
-        }
+        })
+        out.row_anchor = geo["row_anchor"]   # anchor of every matched row (device), for CR_Block's per-anchor means
         if self.conf_perc is not None and self.conf_perc > 0.0:
             out["tr_conf_mask"] = refine_ety(tr_voxel_ety, tr_logits_all.argmax(1), self.conf_perc, num_classes=C)
         else:
@@ -250,8 +257,10 @@ class CR_Block(nn.Module):
         ac = torch.where(ac == 0.0, torch.full_like(ac, 1e-8), ac)
         row = weight * F.kl_div(torch.log(ac), tr, reduction="none").sum(1)
         keep = logit_dict["tr_conf_mask"][:M].to(row.dtype) if self.conf_mask else torch.ones(M, device=dev)
-        anchor_of_row = torch.repeat_interleave(torch.arange(len(sizes), device=dev),
-                                                torch.as_tensor(sizes, device=dev))
+        anchor_of_row = getattr(logit_dict, "row_anchor", None)
+        if anchor_of_row is None or anchor_of_row.numel() != M:
+            anchor_of_row = torch.repeat_interleave(torch.arange(len(sizes), device=dev),
+                                                    torch.as_tensor(sizes, device=dev), output_size=M)
         num = torch.zeros(len(sizes), dtype=row.dtype, device=dev).index_add(0, anchor_of_row, row * keep)
         den = torch.zeros(len(sizes), dtype=row.dtype, device=dev).index_add(0, anchor_of_row, keep)
         return (num / den).sum() / len(sizes)

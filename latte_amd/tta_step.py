@@ -109,10 +109,31 @@ def shard_scan_offset(rank: int, scans_per_rank: int) -> int:
     return rank * scans_per_rank
 
 
+def _record_stream_tree(obj, stream, seen=None) -> None:
+    """tensor.record_stream(stream) for every tensor reachable from obj (dicts, sequences, attribute dicts): memory
+    allocated on a side stream and used on `stream` must not be handed out again before `stream` is done with it."""
+    if seen is None:
+        seen = set()
+    if obj is None or id(obj) in seen or isinstance(obj, (int, float, str, bool)):
+        return
+    seen.add(id(obj))
+    if torch.is_tensor(obj):
+        if obj.is_cuda:
+            obj.record_stream(stream)
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            _record_stream_tree(v, stream, seen)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            _record_stream_tree(v, stream, seen)
+    elif hasattr(obj, "__dict__") and type(obj).__module__.startswith("latte_amd"):
+        _record_stream_tree(vars(obj), stream, seen)
+
+
 class LatteStep:
     def __init__(self, model_3d: nn.Module, num_classes: int, hr_cfg: Dict, lr: float = 1e-3, conf_perc=None,
                  lambda_hr_23: float = 0.3, lambda_hr_32: float = 0.3, lambda_ety_ps: float = 1.0, class_weights=None,
-                 process_group=None, overlap: bool = False, hr_side_stream: bool = True):
+                 process_group=None, side_stream: bool = True):
         self.model = configure_model_norm(model_3d, reset_dropout=True)
         self.ema_model = create_ema_model(self.model)
         self.hr = HR_Block(**hr_cfg)
@@ -126,16 +147,22 @@ class LatteStep:
         self.pg = process_group
         self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
         self.timers = None
-        self.overlap = overlap      # teacher and student forward on two streams (same results, see forward_backward)
-        self._streams = None
-        # HR_Block.geometry (points and poses only, all of the block's host syncs) on a side stream while the two
-        # forward passes execute on the main stream
-        self.hr_side_stream = hr_side_stream
+        self.trace = None
+        # input-only, sync-heavy work (index structures, in-FOV tables, HR_Block.geometry) on a side stream: see
+        # forward_backward
+        self.hr_side_stream = side_stream
         self._side = None
 
     # -------------------------------------------------------------------------------------------------
     def _tick(self, name: str):
         """segment timer for tools/step_breakdown.py (synchronises; off unless self.timers is a dict)"""
+        if self.trace is not None:
+            # non-synchronising trace for tools/timeline.py: host time of the call + an event on the current stream
+            import time
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.trace.append((name, time.perf_counter(), ev))
+            return
         if self.timers is None:
             return
         import time
@@ -144,80 +171,90 @@ class LatteStep:
         self.timers[name] = self.timers.get(name, 0.0) + (now - self._t_last)
         self._t_last = now
 
+    def _batch_tables(self, batch: Dict) -> Dict:
+        """Per-batch index tables that depend on the inputs only: in-FOV point indices (the bool maps of
+        latte/data/utils/all_to_partial.py:4-37 turned into one index vector, so later gathers/scatters need no host
+        sync), the per-scan in-FOV points, the unique-voxel -> raw-point gather index of inverse_to_all."""
+        pc2img = batch["pc2img_idx"]
+        mask = torch.cat(list(pc2img), 0)
+        fov_idx = torch.nonzero(mask).squeeze(1)      # the one host sync of the table (on the stream it is built on)
+        counts = [int(t.shape[0]) for t in batch["img_indices"]]
+        assert sum(counts) == fov_idx.numel(), "img_indices and pc2img_idx disagree"
+        ori_all = torch.cat([p.reshape(-1, 3) for p in batch["ori_points"]], 0)
+        ori_2d = list(torch.split(ori_all[fov_idx], counts, 0))
+        sizes = [int(i.shape[0]) for i in batch["indices"]]
+        inv, off = [], 0
+        for n, iv in zip(sizes, batch["inverse_map"]):
+            iv = iv if torch.is_tensor(iv) else torch.as_tensor(iv)
+            inv.append(iv.to(mask.device, dtype=torch.int64) + off)
+            off += n
+        return {"mask": mask, "fov_idx": fov_idx, "ori_2d": ori_2d, "inv_all": torch.cat(inv, 0)}
+
     def forward_backward(self, batch: Dict):
-        """-> dict of losses.  batch: see latte_amd.workload.build_batch."""
+        """-> dict of losses.  batch: see latte_amd.workload.build_batch.
+
+        Stream plan (side stream on, the default): everything that depends on the INPUTS only and needs host syncs --
+        the index structures of the backbone, the in-FOV tables, the geometry of both HR calls -- runs on a
+        high-priority side stream; the main stream carries the two forwards, the HR feature kernels, the losses and
+        the backward without a single host sync, so the host stays ahead of the GPU for the whole iteration."""
         if self.timers is not None:
             import time
             torch.cuda.synchronize()
             self._t_last = time.perf_counter()
         extra = {k: batch[k] for k in ("pose", "scene_name", "scan_ID", "img_indices")}
-        pc2img = batch["pc2img_idx"]
         ema_logit_2d = batch["logit_2d_teacher"]
         preds_2d = {"seg_logit": batch["logit_2d_student"]}
-        ori_2d = [p[m] for p, m in zip(batch["ori_points"], pc2img)]
         main = torch.cuda.current_stream()
         side = None
         if self.hr_side_stream and self.timers is None:
             if self._side is None:
-                self._side = torch.cuda.Stream()
+                self._side = torch.cuda.Stream(priority=-1)  # small dependent kernels: ahead of the big ones
             side = self._side
-            ev_in = torch.cuda.Event()
-            ev_in.record(main)   # inputs of the geometry are ready; earlier steps' work on `main` is before this point
-        if self.overlap and self.timers is None:
-            # index structures once, then teacher and student forward side by side on two HIP streams: the two passes
-            # are independent, and most of their kernels (BN, point<->voxel, coarse-level convs) are far too small to
-            # fill 256 CUs on their own
-            self.model.net_3d.prepare(batch["lidar"])
-            main = torch.cuda.current_stream()
-            if self._streams is None:
-                self._streams = (torch.cuda.Stream(), torch.cuda.Stream())
-            s_t, s_s = self._streams
-            s_t.wait_stream(main)
-            s_s.wait_stream(main)
-            with torch.cuda.stream(s_t), torch.no_grad():
-                ema3d = self.ema_model(batch)
-                ema3d["seg_logit"] = inverse_to_all(ema3d["seg_logit"], batch)
-            with torch.cuda.stream(s_s):
-                preds_3d = self.model(batch)
-                preds_3d["seg_logit"] = inverse_to_all(preds_3d["seg_logit"], batch)
-            main.wait_stream(s_t)
-            main.wait_stream(s_s)
-            for t in (ema3d["seg_logit"], preds_3d["seg_logit"]):
-                t.record_stream(main)
-            with torch.no_grad():
-                pc2img_mask, ema_logit_3d = pc2img_logit(ema3d["seg_logit"], pc2img)
-        else:
-            with torch.no_grad():
-                ema3d = self.ema_model(batch)
-                ema3d["seg_logit"] = inverse_to_all(ema3d["seg_logit"], batch)
-                pc2img_mask, ema_logit_3d = pc2img_logit(ema3d["seg_logit"], pc2img)
-            self._tick("teacher_fwd")
-            preds_3d = self.model(batch)
-            preds_3d["seg_logit"] = inverse_to_all(preds_3d["seg_logit"], batch)
-            self._tick("student_fwd")
 
-        a2 = dict(preds_2d, ori_points=ori_2d, **extra)
-        h2 = dict(seg_logit=ema_logit_2d, ori_points=ori_2d, **extra)
-        a3 = dict(seg_logit=preds_3d["seg_logit"], ori_points=batch["ori_points"], **extra)
-        h3 = dict(seg_logit=ema3d["seg_logit"], ori_points=batch["ori_points"], **extra)
+        def hr_inputs(tab):
+            a2 = dict(preds_2d, ori_points=tab["ori_2d"], **extra)
+            h2 = dict(seg_logit=ema_logit_2d, ori_points=tab["ori_2d"], **extra)
+            a3 = dict(ori_points=batch["ori_points"], **extra)
+            h3 = dict(ori_points=batch["ori_points"], **extra)
+            return a2, h2, a3, h3
+
+        if side is not None:
+            with torch.cuda.stream(side):
+                tab = self._batch_tables(batch)
+                self.model.net_3d.prepare(batch["lidar"])
+            main.wait_stream(side)
+            _record_stream_tree(batch["lidar"]._lt_cache, main)
+            _record_stream_tree(tab, main)
+        else:
+            tab = self._batch_tables(batch)
+        fov_idx = tab["fov_idx"]
+        a2, h2, a3, h3 = hr_inputs(tab)
+
+        with torch.no_grad():
+            ema3d = self.ema_model(batch)
+            ema3d["seg_logit"] = ema3d["seg_logit"][tab["inv_all"]]     # inverse_to_all
+            ema_logit_3d = ema3d["seg_logit"][fov_idx]                  # pc2img_logit
+        self._tick("teacher_fwd")
         geo23 = geo32 = None
         if side is not None:
-            # the forwards above are queued on the main stream; the sync-heavy geometry of both HR calls runs beside
-            # them (its inputs were ready at ev_in)
-            side.wait_event(ev_in)
+            # the teacher forward is queued on the main stream; the sync-heavy geometry of both HR calls runs beside it
             with torch.cuda.stream(side):
                 geo23 = self.hr.geometry(a2, "2D", h3, "3D")
                 geo32 = self.hr.geometry(a3, "3D", h2, "2D")
+        preds_3d = self.model(batch)
+        preds_3d["seg_logit"] = preds_3d["seg_logit"][tab["inv_all"]]
+        self._tick("student_fwd")
+        if side is not None:
             main.wait_stream(side)
-            for geo in (geo23, geo32):
-                for t in geo.values():
-                    if torch.is_tensor(t):
-                        t.record_stream(main)
+            _record_stream_tree(geo23, main)
+            _record_stream_tree(geo32, main)
+        a3["seg_logit"] = preds_3d["seg_logit"]
+        h3["seg_logit"] = ema3d["seg_logit"]
         hr23 = self.hr(a2, "2D", h3, "3D", geo=geo23)
         hr32 = self.hr(a3, "3D", h2, "2D", geo=geo32)
         self._tick("hr_x2")
 
-        # ---- pseudo labels (latte.py:207-238)
+        # ---- pseudo labels (latte.py:207-238); [pc2img_mask] indexing of the reference = gathers/scatters by fov_idx
         with torch.no_grad():
             probs_2d = F.softmax(ema_logit_2d, 1)
             all_probs_3d = F.softmax(ema3d["seg_logit"], 1)
@@ -232,11 +269,11 @@ class LatteStep:
             pc2 = torch.where(v2, st2, pc2)
             pc3 = torch.where(v3, st3, pc3)
             rv2, rv3 = torch.exp(-pc2), torch.exp(-pc3)
-            rv3m = rv3[pc2img_mask]
+            rv3m = rv3[fov_idx]
             w2 = rv2 / (rv2 + rv3m)
             w3 = rv3m / (rv2 + rv3m)
             ps_prob = all_probs_3d
-            ps_prob[pc2img_mask] = w2.unsqueeze(1) * probs_2d + w3.unsqueeze(1) * probs_3d
+            ps_prob.index_copy_(0, fov_idx, w2.unsqueeze(1) * probs_2d + w3.unsqueeze(1) * probs_3d)
             ps_conf, ps_label = ps_prob.max(1)
             ps_label = refine_pseudo_labels(ps_conf, ps_label, num_classes=self.num_classes)
 
@@ -248,7 +285,7 @@ class LatteStep:
         hr32.update({"ac_pc_ety": pc3, "tr_pc_ety": pc2})
         l32 = self.cr(hr32)
         loss_3d.append(self.lam32 * l32)
-        pl2 = F.cross_entropy(preds_2d["seg_logit"], ps_label[pc2img_mask].long(), weight=self.class_weights)
+        pl2 = F.cross_entropy(preds_2d["seg_logit"], ps_label[fov_idx].long(), weight=self.class_weights)
         pl3 = F.cross_entropy(preds_3d["seg_logit"], ps_label.long(), weight=self.class_weights)
         loss_2d.append(pl2)
         loss_3d.append(pl3)
@@ -261,6 +298,7 @@ class LatteStep:
         allreduce_mean_grads(self.params, self.world, self.pg)
 
     def step(self, batch: Dict):
+        self._tick("step_begin")
         # one TTA iteration = one new batch: index structures are built once per iteration (by the teacher forward) and
         # shared with the student forward, never carried over from an earlier iteration
         batch["lidar"]._lt_cache = None
