@@ -19,6 +19,7 @@
 //    conflict-free ds_read_b128 (lane-linear image).
 //  * offsets with no neighbour in the 64-row tile are skipped for the whole workgroup, offsets with no neighbour
 //    in a wave's 16-row strip skip that wave's MFMAs (wave-uniform branch).
+#include <hip/hip_ext.h>
 #include "common.h"
 #include "../../include/latte_hip.h"
 
@@ -275,8 +276,16 @@ struct PlanArgs {
   const int* torder;                  // [T] tiles by descending work
   float* out;
   int Vin, Vout, Cin, Cout, K;
-  float* partial;                     // optional [gridDim.x][2][Cout]: per-workgroup column sums of out and out^2
+  float* partial;                     // optional [row workgroups][2][Cout]: per-workgroup column sums of out and out^2
+  int gx;                             // split-k: row workgroups (the grid is 1-D there, see the XCD mapping)
+  int swz;                            // split-k: XCD-aware workgroup mapping on
 };
+
+// events of the armed conv launch timer for the launch being issued (null otherwise): the conv kernels are launched
+// with hipExtLaunchKernelGGL, which stamps them with the dispatch's own begin / end times (no extra barrier packets)
+static hipEvent_t g_conv_ev0 = nullptr, g_conv_ev1 = nullptr;
+#define LT_CONV_LAUNCH(kernel, grid, block, stream, ...) \
+  hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, g_conv_ev0, g_conv_ev1, 0, __VA_ARGS__)
 
 typedef __attribute__((address_space(3))) void* lt_lds_ptr;
 typedef __attribute__((address_space(1))) const void* lt_glb_ptr;
@@ -450,10 +459,10 @@ static int launch_plan(const PlanArgs& a, hipStream_t stream) {
   // two plan tiles per workgroup (half the weight traffic per flop) once the grid still fills the chip a few times over
   if (T * cb >= 2 * 4 * 256) {
     dim3 grid((unsigned)((T + 1) / 2), (unsigned)cb);
-    hipLaunchKernelGGL((k_spconv_plan<NT, UB, 2>), grid, dim3(256), 0, stream, a);
+    LT_CONV_LAUNCH((k_spconv_plan<NT, UB, 2>), grid, dim3(256), stream, a);
   } else {
     dim3 grid((unsigned)T, (unsigned)cb);
-    hipLaunchKernelGGL((k_spconv_plan<NT, UB, 1>), grid, dim3(256), 0, stream, a);
+    LT_CONV_LAUNCH((k_spconv_plan<NT, UB, 1>), grid, dim3(256), stream, a);
   }
   LT_LAUNCH_CHECK();
   return LT_OK;
@@ -491,11 +500,27 @@ __global__ __launch_bounds__(64 * W) void k_spconv_rf(PlanArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, q = lane >> 4;
   // workgroups that own at most one plan tile are dispatched heaviest tile first
-  const int64_t tile0 = TPW == 1 ? (int64_t)a.torder[blockIdx.x / PARTS] : (int64_t)blockIdx.x * TPW;
-  const int s0 = PARTS == 1 ? 0 : (int)(blockIdx.x % PARTS) * SR;  // first strip inside the plan tile
+  // (bx, by) = (row workgroup, column group).  Split-k launches a 1-D grid and maps it XCD-aware: hardware hands
+  // consecutive workgroups to the 8 XCDs round-robin, so workgroup L runs on XCD L % 8; the column groups of one row
+  // tile (same gathered rows) are made consecutive ON ONE XCD, so its L2 serves the gather to all of them.
+  unsigned bx = blockIdx.x, by = blockIdx.y;
+  if constexpr (SK) {
+    const unsigned gy = a.Cout / (16 * NTW);
+    if (a.swz) {
+      const unsigned L = blockIdx.x, i = L >> 3;
+      bx = (i / gy) * 8 + (L & 7);
+      by = i % gy;
+    } else {
+      bx = blockIdx.x % a.gx;
+      by = blockIdx.x / a.gx;
+    }
+    if (bx >= (unsigned)a.gx || by >= gy) return;  // padding of the 1-D grid
+  }
+  const int64_t tile0 = TPW == 1 ? (int64_t)a.torder[bx / PARTS] : (int64_t)bx * TPW;
+  const int s0 = PARTS == 1 ? 0 : (int)(bx % PARTS) * SR;  // first strip inside the plan tile
   const int64_t T = ((int64_t)a.Vout + LT_TM - 1) / LT_TM;
   const int J = a.Cin / 16, NTt = a.Cout / 16;
-  const int nt0 = SK ? blockIdx.y * NTW : (blockIdx.y * W + wave) * NTW;
+  const int nt0 = SK ? by * NTW : (by * W + wave) * NTW;
 
   if (wave == 0) {
     unsigned int act = 0u;
@@ -662,7 +687,7 @@ __global__ __launch_bounds__(64 * W) void k_spconv_rf(PlanArgs a) {
           float t = 0.f;
 #pragma unroll
           for (int w = 0; w < W; ++w) t += redf[((w * NTW + n) * 2 + which) * 16 + r];
-          a.partial[((int64_t)blockIdx.x * 2 + which) * a.Cout + 16 * (nt0 + n) + r] = t;
+          a.partial[((int64_t)bx * 2 + which) * a.Cout + 16 * (nt0 + n) + r] = t;
         }
       }
     }
@@ -715,7 +740,7 @@ static void launch_rf_one(const PlanArgs& a, int gy, hipStream_t stream) {
   } else {
     gx = (unsigned)(((a.Vout + LT_TM - 1) / LT_TM) * (4 / SR));
   }
-  hipLaunchKernelGGL((k_spconv_rf<SR, NTW, W>), dim3(gx, (unsigned)gy), dim3(64 * W), 0, stream, a);
+  LT_CONV_LAUNCH((k_spconv_rf<SR, NTW, W>), dim3(gx, (unsigned)gy), dim3(64 * W), stream, a);
 }
 
 template <int SR, int NTW, int W>
@@ -723,7 +748,11 @@ static void launch_sk_one(const PlanArgs& a, hipStream_t stream) {
   unsigned gx;
   if (SR >= 4) gx = (unsigned)((a.Vout + 16 * SR - 1) / (16 * SR));
   else gx = (unsigned)(((a.Vout + LT_TM - 1) / LT_TM) * (4 / SR));
-  hipLaunchKernelGGL((k_spconv_rf<SR, NTW, W, true>), dim3(gx, (unsigned)(a.Cout / (16 * NTW))), dim3(64 * W), 0, stream, a);
+  PlanArgs b = a;
+  b.gx = (int)gx;
+  const unsigned gy = (unsigned)(a.Cout / (16 * NTW));
+  const unsigned total = ((gx + 7) / 8) * 8 * gy;
+  LT_CONV_LAUNCH((k_spconv_rf<SR, NTW, W, true>), dim3(total), dim3(64 * W), stream, b);
 }
 
 // split-k launch: sr in {1,2,4}, ntw in {1,2,3,4,6,8}, w in {2,4,8}
@@ -779,7 +808,7 @@ static int launch_rf(const PlanArgs& a, int sr, hipStream_t stream) {
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Conv launch timer (bench.py's roofline leg): while armed, every sparse-conv kernel launch of this library is bracketed
-// by two hipEvents recorded on the stream the kernel is launched on.  Process-global, one caller thread (as everywhere).
+// by two hipEvents on the stream the kernel is launched on (attached to the dispatch itself, hipExtLaunchKernelGGL).  Process-global, one caller thread (as everywhere).
 struct LtConvTimer {
   hipEvent_t* ev = nullptr;  // 2 * cap
   int32_t* meta = nullptr;   // 4 * cap: Cin, Cout, K, Vout
@@ -797,11 +826,10 @@ struct LtConvTimerScope {
     slot = g_timer.n++;
     int32_t* m = g_timer.meta + 4 * slot;
     m[0] = Cin; m[1] = Cout; m[2] = K; m[3] = (int32_t)Vout;
-    (void)hipEventRecord(g_timer.ev[2 * slot], stream);
+    g_conv_ev0 = g_timer.ev[2 * slot];
+    g_conv_ev1 = g_timer.ev[2 * slot + 1];
   }
-  ~LtConvTimerScope() {
-    if (slot >= 0) (void)hipEventRecord(g_timer.ev[2 * slot + 1], stream);
-  }
+  ~LtConvTimerScope() { g_conv_ev0 = g_conv_ev1 = nullptr; }
 };
 
 extern "C" int lt_conv_timer_begin(int32_t capacity) {
@@ -838,8 +866,8 @@ extern "C" int64_t lt_conv_timer_end(float* ms, int32_t* meta, int64_t capacity)
 }
 
 // Default kernel shape (measured on every level / width of the U-Net, tools/conv_bench.py + tools/cb_sk.sh):
-// the split-k flavour with 4 column tiles per wave (3 for Cout = 48, 96, ...), 32-row workgroups of 4 waves (64 rows
-// when the wave has 3 tiles); 16-row workgroups of 8 waves when that leaves fewer than 4000 waves (coarsest level).
+// the split-k flavour with 4 column tiles per wave (3 for Cout = 48, 96, ...) and 32-row workgroups of 4 waves; 8 waves
+// when that leaves fewer than 6000 waves, and 16-row workgroups below 4000 (the coarsest levels).
 struct LtConvShape {
   int sr, ntw, w;
 };
@@ -847,10 +875,11 @@ static LtConvShape conv_default_shape(int64_t Vout, int Cout) {
   const int ntt = Cout / 16;
   LtConvShape s;
   s.ntw = ntt % 4 == 0 ? 4 : ntt % 3 == 0 ? 3 : ntt % 2 == 0 ? 2 : 1;
-  s.sr = s.ntw == 3 ? 4 : 2;
+  s.sr = 2;
   s.w = 4;
   const int64_t waves = ((Vout + 16 * s.sr - 1) / (16 * s.sr)) * (ntt / s.ntw) * s.w;
   if (waves < 4000) { s.sr = 1; s.w = 8; }
+  else if (waves < 6000) s.w = 8;
   return s;
 }
 static int64_t rf_grid_x(int64_t Vout, int sr) {
@@ -897,7 +926,7 @@ static int spconv_plan_impl(const float* in, const float* packed, const void* pl
   LT_REQUIRE(packed && plan && out && (Vin == 0 || in), LT_ERR_ARG, "lt_spconv_plan_fwd: null pointer");
   LT_REQUIRE(((uintptr_t)plan & 15) == 0, LT_ERR_ARG, "lt_spconv_plan_fwd: plan must be 16-byte aligned");
   LtPlanView pv = lt_plan_view(const_cast<void*>(plan), K, Vout);
-  PlanArgs a{in, packed, pv.tnbr, pv.tmask, pv.order, pv.torder, out, (int)Vin, (int)Vout, Cin, Cout, K, partial};
+  PlanArgs a{in, packed, pv.tnbr, pv.tmask, pv.order, pv.torder, out, (int)Vin, (int)Vout, Cin, Cout, K, partial, 0, 1};
   LtConvTimerScope timed(stream, Cin, Cout, K, Vout);
   const int ntt = Cout / 16;
   LT_REQUIRE(!(partial && variant != 0), LT_ERR_ARG, "lt_spconv_plan_fwd: statistics need the default variant");
@@ -913,6 +942,11 @@ static int spconv_plan_impl(const float* in, const float* packed, const void* pl
     if (ntt % 3 == 0) return launch_plan<3, 4>(a, stream);
     if (ntt % 2 == 0) return launch_plan<2, 8>(a, stream);
     return launch_plan<1, 8>(a, stream);
+  }
+  if (variant >= 10000) {  // 10000 + split-k code: the same without the XCD-aware workgroup mapping (A/B measurements)
+    a.swz = 0;
+    variant -= 10000;
+    LT_REQUIRE(variant >= 1000, LT_ERR_ARG, "lt_spconv_plan_fwd_v: unknown variant %d", variant + 10000);
   }
   if (variant >= 1000) {  // split-k: 1000 + 100*SR + 10*NTW + W
     const int v = variant - 1000;
@@ -944,8 +978,8 @@ extern "C" int lt_spconv_plan_fwd(const float* in, const float* packed, const vo
 template <int NT>
 static int launch_conv(const ConvArgs& a, hipStream_t stream) {
   dim3 grid(lt_cdiv(a.Vout, LT_TM), a.Cout / (16 * NT));
-  if (a.Cin % 16 == 0) hipLaunchKernelGGL(k_spconv_vec<NT>, grid, dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL(k_spconv_scalar<NT>, grid, dim3(256), 0, stream, a);
+  if (a.Cin % 16 == 0) LT_CONV_LAUNCH(k_spconv_vec<NT>, grid, dim3(256), stream, a);
+  else LT_CONV_LAUNCH(k_spconv_scalar<NT>, grid, dim3(256), stream, a);
   LT_LAUNCH_CHECK();
   return LT_OK;
 }
