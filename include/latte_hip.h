@@ -123,7 +123,8 @@ int lt_spconv_plan_fwd(const float* in, const float* packed, const void* plan, f
  * 1 = LDS-DMA staged kernel, 100*SR + NTW = register-fed kernel, one k-ascending chain per output element (bitwise equal
  * to lt_spconv_fwd), SR (1|2|4|8) 16-row strips per workgroup, NTW (1|2|4) column tiles per wave;
  * 1000 + 100*SR + 10*NTW + W = split-k: W (2|4|8) waves share the slab list of SR (1|2|4) strips x NTW (1|2|3|4|6|8)
- * column tiles and add their partial sums in wave order (deterministic; differs from the single chain by fp32 rounding) */
+ * column tiles and add their partial sums in wave order (deterministic; differs from the single chain by fp32 rounding);
+ * 10000 + a split-k code = the same without the XCD-aware workgroup mapping (A/B measurements) */
 int lt_spconv_plan_fwd_v(const float* in, const float* packed, const void* plan, float* out, int64_t Vin, int64_t Vout,
                          int32_t Cin, int32_t Cout, int32_t K, int32_t variant, lt_stream_t stream);
 /* lt_spconv_plan_fwd that also leaves, in stats_ws (lt_spconv_stats_bytes), the column sums of the rows each workgroup b
