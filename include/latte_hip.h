@@ -141,6 +141,7 @@ int lt_spconv_plan_fwd_stats(const float* in, const float* packed, const void* p
  * lt_conv_bn_fwd/bwd) is bracketed by two hipEvents on the launch stream.  lt_conv_timer_end [sync] waits for them and
  * returns the number of launches n (<= capacity), ms[i] = duration, meta[4*i..] = Cin, Cout, K, Vout of launch i. */
 int lt_conv_timer_begin(int32_t capacity);
+int lt_conv_timer_arm(int32_t on); /* pause (0) / resume (1) between begin and end: time a sample of the launches */
 int64_t lt_conv_timer_end(float* ms, int32_t* meta, int64_t capacity);
 
 /* ------------------------------------------------------------------ BatchNorm(batch stats)+ReLU+residual
@@ -193,6 +194,19 @@ int lt_devoxelize_fwd(const float* feats, const int32_t* idx, const float* w, fl
                       int64_t V, lt_stream_t stream);
 int lt_devoxelize_bwd(const float* gout, const int32_t* idx, const float* w, float* gfeats, int64_t N, int32_t C,
                       int64_t V, lt_stream_t stream);
+
+/* The two scatter-adds above (spvoxelize forward, spdevoxelize backward) as atomic-free gathers over a CSR of the index
+ * map, built once per map: perm[off[v] .. off[v+1]) = the entries e (ascending) with key[e] == v; keys outside [0,V) are
+ * dropped.  Summation order = a sequential index_add's (the CPU order of torchsparse's fallbacks). */
+int64_t lt_csr_workspace_bytes(int64_t n);
+int lt_csr_build(const int32_t* key, int64_t n, int64_t V, void* ws, int64_t ws_bytes, int32_t* perm /*[n]*/,
+                 int32_t* off /*[V+1]*/, lt_stream_t stream);
+/* = lt_voxelize_fwd with key = idx[N] (counts = row lengths) */
+int lt_voxelize_csr_fwd(const float* feats, const int32_t* perm, const int32_t* off, float* out, int64_t V, int32_t C,
+                        lt_stream_t stream);
+/* = lt_devoxelize_bwd with key = idx[N*8] flattened (entry e = 8*point + corner), w[N*8] */
+int lt_devoxelize_csr_bwd(const float* gout, const int32_t* perm, const int32_t* off, const float* w, float* gfeats,
+                          int64_t V, int32_t C, lt_stream_t stream);
 
 /* ------------------------------------------------------------------ ST-voxel aggregation (HR_Block / CR_Block)
  * see latte/models/hr_module.py:135-331 and :344-420; declared in the second half of this header */

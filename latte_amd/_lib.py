@@ -45,6 +45,7 @@ SIGNATURES = {
     "lt_spconv_plan_fwd_v": (ctypes.c_int, [P, P, P, P, I64, I64, I32, I32, I32, I32, P]),
     "lt_spconv_stat_blocks": (I64, [I64, I32]),
     "lt_conv_timer_begin": (ctypes.c_int, [I32]),
+    "lt_conv_timer_arm": (ctypes.c_int, [I32]),
     "lt_conv_timer_end": (I64, [P, P, I64]),
     "lt_spconv_plan_fwd_stats": (ctypes.c_int, [P, P, P, P, I64, I64, I32, I32, I32, P, P]),
     "lt_bn_finalize_sums": (ctypes.c_int, [P, I64, I32, P, P, P]),
@@ -66,6 +67,10 @@ SIGNATURES = {
     "lt_calc_ti_weights": (ctypes.c_int, [P, P, I64, I32, P, P]),
     "lt_devoxelize_fwd": (ctypes.c_int, [P, P, P, P, I64, I32, I64, P]),
     "lt_devoxelize_bwd": (ctypes.c_int, [P, P, P, P, I64, I32, I64, P]),
+    "lt_csr_workspace_bytes": (I64, [I64]),
+    "lt_csr_build": (ctypes.c_int, [P, I64, I64, P, I64, P, P, P]),
+    "lt_voxelize_csr_fwd": (ctypes.c_int, [P, P, P, P, I64, I32, P]),
+    "lt_devoxelize_csr_bwd": (ctypes.c_int, [P, P, P, P, P, I64, I32, P]),
     # include/latte_hip_st.h
     "lt_softmax_entropy": (ctypes.c_int, [P, I64, I32, P, P, P]),
     "lt_softmax_bwd": (ctypes.c_int, [P, P, I64, I32, P, P]),

@@ -3,6 +3,7 @@
 // All HBM-bound: one lane per 16-B channel group, rows contiguous across lanes.
 #include "common.h"
 #include "../../include/latte_hip.h"
+#include <rocprim/device/device_radix_sort.hpp>
 
 // ---------------------------------------------------------------- spvoxelize (average pooling of points into voxels)
 // out[idx[i], :] += feats[i, :] / counts[idx[i]]   -- same divide-then-add order as the reference kernel.
@@ -163,5 +164,125 @@ extern "C" int lt_devoxelize_bwd(const float* gout, const int32_t* idx, const fl
     hipLaunchKernelGGL(k_devox_bwd, dim3(lt_grid(N * C, 256)), dim3(256), 0, stream, gout, idx, w, gfeats, N, C, V);
     LT_LAUNCH_CHECK();
   }
+  return LT_OK;
+}
+
+// ---------------------------------------------------------------- CSR of a scatter index (atomic-free scatter-adds)
+// The two scatter-adds above (spvoxelize forward, spdevoxelize backward) as gathers: the entries e with key[e] = v are
+// listed per target row v (perm[off[v] .. off[v+1]), ascending e), built once per index map by one stable radix sort.
+// Summation order = ascending entry = the order of a sequential index_add: deterministic, no memset, no atomics.
+__global__ void k_csr_keys(const int* __restrict__ key, int64_t n, int V, unsigned int* __restrict__ k2, int* __restrict__ iota) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const int k = key[e];
+    k2[e] = (k < 0 || k >= V) ? (unsigned int)V : (unsigned int)k;  // dropped entries sort behind every row
+    iota[e] = (int)e;
+  }
+}
+// off[v] = first position of a key >= v in the sorted keys, v = 0..V
+__global__ void k_csr_offsets(const unsigned int* __restrict__ sk, int64_t n, int V, int* __restrict__ off) {
+  for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v <= V; v += (int64_t)gridDim.x * blockDim.x) {
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (sk[mid] < (unsigned int)v) lo = mid + 1; else hi = mid;
+    }
+    off[v] = (int)lo;
+  }
+}
+
+static int64_t csr_sort_bytes(int64_t n) {
+  size_t b = 0;
+  unsigned int* k = nullptr;
+  int* v = nullptr;
+  (void)rocprim::radix_sort_pairs<LtSortConfig>(nullptr, b, k, k, v, v, (size_t)(n > 0 ? n : 1), 0, 32, (hipStream_t)0);
+  return (int64_t)b;
+}
+
+extern "C" int64_t lt_csr_workspace_bytes(int64_t n) {
+  const int64_t m = n > 0 ? n : 1;
+  return lt_align_up(csr_sort_bytes(m), 256) + 3 * lt_align_up(m * 4, 256) + 256;
+}
+
+extern "C" int lt_csr_build(const int32_t* key, int64_t n, int64_t V, void* ws, int64_t ws_bytes, int32_t* perm, int32_t* off,
+                            hipStream_t stream) {
+  LT_REQUIRE(n >= 0 && V >= 0 && n < INT32_MAX && V < INT32_MAX, LT_ERR_RANGE, "lt_csr_build: bad sizes");
+  LT_REQUIRE(off && (n == 0 || (key && perm)), LT_ERR_ARG, "lt_csr_build: null pointer");
+  LT_REQUIRE(ws && ws_bytes >= lt_csr_workspace_bytes(n), LT_ERR_WORKSPACE, "lt_csr_build: workspace too small");
+  if (n == 0) {
+    LT_CHECK_HIP(hipMemsetAsync(off, 0, (V + 1) * 4, stream));
+    return LT_OK;
+  }
+  LtArena ar(ws, ws_bytes);
+  size_t sbs = (size_t)csr_sort_bytes(n);
+  void* tmp = ar.take(sbs);
+  unsigned int* k2 = (unsigned int*)ar.take(n * 4);
+  unsigned int* sk = (unsigned int*)ar.take(n * 4);
+  int* iota = (int*)ar.take(n * 4);
+  hipLaunchKernelGGL(k_csr_keys, dim3(lt_grid(n, 256)), dim3(256), 0, stream, key, n, (int)V, k2, iota);
+  LT_LAUNCH_CHECK();
+  unsigned bits = 1;
+  while ((1ll << bits) <= V) ++bits;
+  LT_CHECK_HIP(rocprim::radix_sort_pairs<LtSortConfig>(tmp, sbs, k2, sk, iota, perm, (size_t)n, 0, bits, stream));
+  hipLaunchKernelGGL(k_csr_offsets, dim3(lt_grid(V + 1, 256)), dim3(256), 0, stream, sk, n, (int)V, off);
+  LT_LAUNCH_CHECK();
+  return LT_OK;
+}
+
+// out[v,:] = sum_{j in row v} feats[perm[j],:] / (row length)      (divide, then add, ascending point: as k_voxelize_fwd)
+__global__ void k_voxelize_csr(const float* __restrict__ f, const int* __restrict__ perm, const int* __restrict__ off,
+                               float* __restrict__ out, int64_t V, int C4) {
+  const int64_t total = V * (int64_t)C4;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t v = e / C4;
+    const int c4 = (int)(e - v * C4);
+    const int j0 = off[v], j1 = off[v + 1];
+    const float cnt = (float)(j1 - j0);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = j0; j < j1; ++j) {
+      const float4 x = reinterpret_cast<const float4*>(f + (int64_t)perm[j] * C4 * 4)[c4];
+      acc.x += x.x / cnt; acc.y += x.y / cnt; acc.z += x.z / cnt; acc.w += x.w / cnt;
+    }
+    reinterpret_cast<float4*>(out)[e] = acc;
+  }
+}
+
+extern "C" int lt_voxelize_csr_fwd(const float* feats, const int32_t* perm, const int32_t* off, float* out, int64_t V,
+                                   int32_t C, hipStream_t stream) {
+  LT_REQUIRE(V >= 0 && C >= 4 && C % 4 == 0, LT_ERR_ARG, "lt_voxelize_csr_fwd: bad sizes (C %% 4 == 0 required)");
+  if (V == 0) return LT_OK;
+  LT_REQUIRE(feats && perm && off && out, LT_ERR_ARG, "lt_voxelize_csr_fwd: null pointer");
+  hipLaunchKernelGGL(k_voxelize_csr, dim3(lt_grid(V * (C / 4), 256)), dim3(256), 0, stream, feats, perm, off, out, V, C / 4);
+  LT_LAUNCH_CHECK();
+  return LT_OK;
+}
+
+// gfeats[v,:] = sum_{j in row v} w[perm[j]] * gout[perm[j] / 8,:]   (entries e = 8*point + corner, ascending)
+__global__ void k_devox_csr_bwd(const float* __restrict__ g, const int* __restrict__ perm, const int* __restrict__ off,
+                                const float* __restrict__ w, float* __restrict__ gf, int64_t V, int C4) {
+#pragma clang fp contract(off)
+  const int64_t total = V * (int64_t)C4;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t v = e / C4;
+    const int c4 = (int)(e - v * C4);
+    const int j0 = off[v], j1 = off[v + 1];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = j0; j < j1; ++j) {
+      const int en = perm[j];
+      const float wk = w[en];
+      const float4 x = reinterpret_cast<const float4*>(g + (int64_t)(en >> 3) * C4 * 4)[c4];
+      acc.x += wk * x.x; acc.y += wk * x.y; acc.z += wk * x.z; acc.w += wk * x.w;
+    }
+    reinterpret_cast<float4*>(gf)[e] = acc;
+  }
+}
+
+extern "C" int lt_devoxelize_csr_bwd(const float* gout, const int32_t* perm, const int32_t* off, const float* w,
+                                     float* gfeats, int64_t V, int32_t C, hipStream_t stream) {
+  LT_REQUIRE(V >= 0 && C >= 4 && C % 4 == 0, LT_ERR_ARG, "lt_devoxelize_csr_bwd: bad sizes (C %% 4 == 0 required)");
+  if (V == 0) return LT_OK;
+  LT_REQUIRE(gout && perm && off && w && gfeats, LT_ERR_ARG, "lt_devoxelize_csr_bwd: null pointer");
+  hipLaunchKernelGGL(k_devox_csr_bwd, dim3(lt_grid(V * (C / 4), 256)), dim3(256), 0, stream, gout, perm, off, w, gfeats, V,
+                     C / 4);
+  LT_LAUNCH_CHECK();
   return LT_OK;
 }

@@ -849,6 +849,12 @@ extern "C" int lt_conv_timer_begin(int32_t capacity) {
   return LT_OK;
 }
 
+extern "C" int lt_conv_timer_arm(int32_t on) {
+  LT_REQUIRE(g_timer.cap > 0, LT_ERR_ARG, "lt_conv_timer_arm: call lt_conv_timer_begin first");
+  g_timer.armed = on != 0;
+  return LT_OK;
+}
+
 extern "C" int64_t lt_conv_timer_end(float* ms, int32_t* meta, int64_t capacity) {
   g_timer.armed = false;
   LT_REQUIRE(g_timer.dropped == 0, LT_ERR_RANGE, "lt_conv_timer_end: %d launches beyond the capacity given to lt_conv_timer_begin",

@@ -268,35 +268,47 @@ def batch_norm(x, gamma, beta, eps=1e-5, residual=None, relu=False, stats_out=No
 
 class _Voxelize(Function):
     @staticmethod
-    def forward(ctx, feats, idx, counts):
+    def forward(ctx, feats, idx, counts, csr):
         ctx.n = feats.shape[0]
         ctx.save_for_backward(idx, counts)
+        if csr is not None and feats.shape[1] % 4 == 0:
+            return ops.voxelize_csr_fwd(feats, csr, counts.numel())
         return ops.voxelize_fwd(feats, idx, counts)
 
     @staticmethod
     def backward(ctx, gout):
         idx, counts = ctx.saved_tensors
-        return ops.voxelize_bwd(gout.contiguous(), idx, counts, ctx.n), None, None
+        return ops.voxelize_bwd(gout.contiguous(), idx, counts, ctx.n), None, None, None
 
 
-def spvoxelize(feats, idx, counts):
-    """F.spvoxelize (latte/models/torchsparse_utils.py:20,23,54); idx any int dtype, counts int32."""
-    return _Voxelize.apply(feats.contiguous(), idx.to(torch.int32).contiguous(), counts.to(torch.int32).contiguous())
+def _i32(t: torch.Tensor) -> torch.Tensor:
+    return t if t.dtype == torch.int32 and t.is_contiguous() else t.to(torch.int32).contiguous()
+
+
+def spvoxelize(feats, idx, counts, csr=None):
+    """F.spvoxelize (latte/models/torchsparse_utils.py:20,23,54); idx any int dtype, counts int32.  csr (optional):
+    ops.csr_build(idx, V) of this map -> the atomic-free kernel."""
+    return _Voxelize.apply(feats.contiguous(), _i32(idx), _i32(counts), csr)
 
 
 class _Devoxelize(Function):
     @staticmethod
-    def forward(ctx, feats, idx, w):
+    def forward(ctx, feats, idx, w, csr):
         ctx.v = feats.shape[0]
+        ctx.csr = csr
         ctx.save_for_backward(idx, w)
         return ops.devoxelize_fwd(feats, idx, w)
 
     @staticmethod
     def backward(ctx, gout):
         idx, w = ctx.saved_tensors
-        return ops.devoxelize_bwd(gout.contiguous(), idx, w, ctx.v), None, None
+        csr = ctx.csr() if callable(ctx.csr) else ctx.csr
+        if csr is not None and gout.shape[1] % 4 == 0:
+            return ops.devoxelize_csr_bwd(gout.contiguous(), csr, w, ctx.v), None, None, None
+        return ops.devoxelize_bwd(gout.contiguous(), idx, w, ctx.v), None, None, None
 
 
-def spdevoxelize(feats, idx, w):
-    """F.spdevoxelize (latte/models/torchsparse_utils.py:81,93); idx [N,8] any int dtype, w [N,8] fp32."""
-    return _Devoxelize.apply(feats.contiguous(), idx.to(torch.int32).contiguous(), w.contiguous())
+def spdevoxelize(feats, idx, w, csr=None):
+    """F.spdevoxelize (latte/models/torchsparse_utils.py:81,93); idx [N,8] any int dtype, w [N,8] fp32.  csr (optional):
+    ops.csr_build(idx.view(-1), V) of this map, or a callable returning it -> the atomic-free backward kernel."""
+    return _Devoxelize.apply(feats.contiguous(), _i32(idx), w.contiguous(), csr)

@@ -14,7 +14,7 @@ from . import _lib
 __all__ = [
     "sphash", "HashTable", "sphashquery", "spcount", "unique_sorted", "pack_xyz_keys", "downsample_coords",
     "kmap_build", "kmap_pairs", "kmap_reverse", "kmap_order", "kmap_plan", "spconv_plan", "pack_weights", "spconv", "bn_stats", "bn_apply",
-    "bn_bwd", "voxelize_fwd", "voxelize_bwd", "calc_ti_weights", "devoxelize_fwd", "devoxelize_bwd",
+    "bn_bwd", "voxelize_fwd", "voxelize_bwd", "calc_ti_weights", "devoxelize_fwd", "devoxelize_bwd", "csr_build", "voxelize_csr_fwd", "devoxelize_csr_bwd",
 ]
 
 
@@ -196,6 +196,11 @@ def conv_timer_begin(capacity: int) -> None:
     _lib.call("lt_conv_timer_begin", int(capacity))
 
 
+def conv_timer_arm(on: bool) -> None:
+    """pause / resume the timer between conv_timer_begin and conv_timer_end"""
+    _lib.call("lt_conv_timer_arm", int(bool(on)))
+
+
 def conv_timer_end():
     """-> (ms float32 [n], meta int32 [n,4] = Cin, Cout, K, Vout), one row per conv kernel launch since conv_timer_begin."""
     import numpy as np
@@ -313,6 +318,38 @@ def voxelize_bwd(gout, idx, counts, N: int):
     V, C = gout.shape
     gf = torch.empty((N, C), dtype=torch.float32, device=gout.device)
     _lib.call("lt_voxelize_bwd", _p(gout), _p(idx), _p(counts), _p(gf), N, C, V, _stream())
+    return gf
+
+
+def csr_build(key: torch.Tensor, V: int):
+    """CSR of a scatter index: key int32 [n] with values in [0,V) (others dropped) -> (perm int32 [n], off int32 [V+1])."""
+    key = _chk(key.reshape(-1), torch.int32, "csr key")
+    n = key.numel()
+    dev = key.device
+    perm = torch.empty(n, dtype=torch.int32, device=dev)
+    off = torch.empty(V + 1, dtype=torch.int32, device=dev)
+    ws = _ws(_lib.load().lt_csr_workspace_bytes(n), dev)
+    _lib.call("lt_csr_build", _p(key), n, int(V), _p(ws), ws.numel(), _p(perm), _p(off), _stream())
+    return perm, off
+
+
+def voxelize_csr_fwd(feats, csr, V: int):
+    feats = _chk(feats, torch.float32, "voxelize feats")
+    perm, off = csr
+    assert off.numel() == V + 1
+    C = feats.shape[1]
+    out = torch.empty((V, C), dtype=torch.float32, device=feats.device)
+    _lib.call("lt_voxelize_csr_fwd", _p(feats), _p(perm), _p(off), _p(out), V, C, _stream())
+    return out
+
+
+def devoxelize_csr_bwd(gout, csr, w, V: int):
+    gout = _chk(gout, torch.float32, "devox_bwd gout")
+    perm, off = csr
+    assert off.numel() == V + 1 and w.numel() == perm.numel()
+    C = gout.shape[1]
+    gf = torch.empty((V, C), dtype=torch.float32, device=gout.device)
+    _lib.call("lt_devoxelize_csr_bwd", _p(gout), _p(perm), _p(off), _p(w), _p(gf), V, C, _stream())
     return gf
 
 

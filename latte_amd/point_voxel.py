@@ -9,7 +9,7 @@ from . import functional as LF
 from . import ops
 from .tensor import PointTensor, SparseTensor
 
-__all__ = ["initial_voxelize", "point_to_voxel", "voxel_to_point", "p2v_index", "v2p_index"]
+__all__ = ["initial_voxelize", "point_to_voxel", "voxel_to_point", "p2v_index", "v2p_index", "v2p_csr"]
 
 
 def initial_voxelize(z: PointTensor, init_res: float, after_res: float, cache: dict | None = None) -> SparseTensor:
@@ -17,20 +17,22 @@ def initial_voxelize(z: PointTensor, init_res: float, after_res: float, cache: d
     coordinates only, so a second forward over the same batch (teacher, then student: latte/tta/tools/latte.py:159,176)
     reuses the voxel set, the point->voxel map and -- through the shared cmaps/kmaps dicts -- every kernel map/plan."""
     if cache is not None and "x0" in cache:
-        new_float_coord, idx_query, counts, inserted_coords, cmaps, kmaps = cache["x0"]
+        new_float_coord, idx_query, counts, inserted_coords, cmaps, kmaps, csr = cache["x0"]
     else:
         new_float_coord = torch.cat([(z.C[:, :3] * init_res) / after_res, z.C[:, -1].view(-1, 1)], 1)
         floor_c = torch.floor(new_float_coord)
         pc_hash = ops.sphash(floor_c.int().contiguous())
         # torch.unique(pc_hash): voxels of x0 are ordered by ascending 60-bit hash
         sparse_hash, _, idx_query = ops.unique_sorted(pc_hash, key_bits=60, want_first=False)
-        counts = ops.spcount(idx_query.int(), sparse_hash.numel())
-        inserted_coords = LF.spvoxelize(floor_c, idx_query, counts)
+        idx_query = idx_query.int()
+        counts = ops.spcount(idx_query, sparse_hash.numel())
+        csr = ops.csr_build(idx_query, sparse_hash.numel())   # points of every voxel, ascending: atomic-free pooling
+        inserted_coords = LF.spvoxelize(floor_c, idx_query, counts, csr)
         inserted_coords = torch.round(inserted_coords).int()
         cmaps, kmaps = {}, {}
         if cache is not None:
-            cache["x0"] = (new_float_coord, idx_query, counts, inserted_coords, cmaps, kmaps)
-    inserted_feat = LF.spvoxelize(z.F, idx_query, counts)
+            cache["x0"] = (new_float_coord, idx_query, counts, inserted_coords, cmaps, kmaps, csr)
+    inserted_feat = LF.spvoxelize(z.F, idx_query, counts, csr)
     new_tensor = SparseTensor(inserted_feat, inserted_coords, 1)
     new_tensor.cmaps, new_tensor.kmaps = cmaps, kmaps
     new_tensor.cmaps.setdefault(new_tensor.stride, new_tensor.coords)
@@ -40,6 +42,7 @@ def initial_voxelize(z: PointTensor, init_res: float, after_res: float, cache: d
     # finds it (same map: the stride-1 cells ARE the voxels of x0) instead of rebuilding it by a hash query
     z.additional_features["idx_query"].setdefault(new_tensor.stride, idx_query)
     z.additional_features["counts"].setdefault(new_tensor.stride, counts)
+    z.additional_features.setdefault("p2v_csr", {})[new_tensor.stride] = csr
     z.C = new_float_coord
     return new_tensor
 
@@ -54,16 +57,18 @@ def p2v_index(x: SparseTensor, z: PointTensor):
     if af is None or af.get("idx_query") is None or af["idx_query"].get(x.s) is None:
         pc_hash = ops.sphash(_cell_coords(z, x.s[0]))
         sparse_hash = ops.sphash(x.C.int().contiguous())
-        idx_query = ops.sphashquery(pc_hash, sparse_hash)
-        counts = ops.spcount(idx_query.int(), x.C.shape[0])
+        idx_query = ops.sphashquery(pc_hash, sparse_hash).int()
+        counts = ops.spcount(idx_query, x.C.shape[0])
         af["idx_query"][x.s] = idx_query
         af["counts"][x.s] = counts
+        af.setdefault("p2v_csr", {})[x.s] = ops.csr_build(idx_query, x.C.shape[0])
     return af["idx_query"][x.s], af["counts"][x.s]
 
 
 def point_to_voxel(x: SparseTensor, z: PointTensor) -> SparseTensor:
     idx_query, counts = p2v_index(x, z)
-    new_tensor = SparseTensor(LF.spvoxelize(z.F, idx_query, counts), x.C, x.s)
+    csr = z.additional_features.get("p2v_csr", {}).get(x.s)
+    new_tensor = SparseTensor(LF.spvoxelize(z.F, idx_query, counts, csr), x.C, x.s)
     new_tensor.cmaps, new_tensor.kmaps = x.cmaps, x.kmaps
     return new_tensor
 
@@ -79,13 +84,31 @@ def v2p_index(x: SparseTensor, z: PointTensor, nearest: bool = False):
     if nearest:
         weights[:, 1:] = 0.0
         idx_query[:, 1:] = -1
-    return idx_query, weights
+    return idx_query.int(), weights
+
+
+def _v2p_csr(af: dict, idx_query_of: dict, s, n_vox: int):
+    cs = af.setdefault("v2p_csr", {})
+    if cs.get(s) is None:
+        cs[s] = ops.csr_build(idx_query_of[s].reshape(-1), n_vox)
+    return cs[s]
+
+
+def v2p_csr(x: SparseTensor, z: PointTensor):
+    """CSR of the devoxelize map of stride x.s (entries 8*point + corner per voxel): the backward of spdevoxelize as an
+    atomic-free gather.  Built on first use and cached with the map."""
+    return _v2p_csr(z.additional_features, z.idx_query, x.s, x.C.shape[0])
 
 
 def voxel_to_point(x: SparseTensor, z: PointTensor, nearest: bool = False) -> PointTensor:
+    csr = None
+    if torch.is_grad_enabled() and x.F.requires_grad:
+        # backward only: looked up (or built) when the gradient arrives
+        af, idxq, s, n_vox = z.additional_features, z.idx_query, x.s, x.C.shape[0]
+        csr = lambda: _v2p_csr(af, idxq, s, n_vox)
     if z.idx_query is None or z.weights is None or z.idx_query.get(x.s) is None or z.weights.get(x.s) is None:
         idx_query, weights = v2p_index(x, z, nearest)
-        new_feat = LF.spdevoxelize(x.F, idx_query, weights)
+        new_feat = LF.spdevoxelize(x.F, idx_query, weights, csr)
         new_tensor = PointTensor(new_feat, z.C, idx_query=z.idx_query, weights=z.weights)
         new_tensor.additional_features = z.additional_features
         new_tensor.idx_query[x.s] = idx_query
@@ -93,7 +116,7 @@ def voxel_to_point(x: SparseTensor, z: PointTensor, nearest: bool = False) -> Po
         z.idx_query[x.s] = idx_query
         z.weights[x.s] = weights
     else:
-        new_feat = LF.spdevoxelize(x.F, z.idx_query.get(x.s), z.weights.get(x.s))
+        new_feat = LF.spdevoxelize(x.F, z.idx_query.get(x.s), z.weights.get(x.s), csr)
         new_tensor = PointTensor(new_feat, z.C, idx_query=z.idx_query, weights=z.weights)
         new_tensor.additional_features = z.additional_features
     return new_tensor

@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from . import sparse_modules as spnn
-from .point_voxel import initial_voxelize, p2v_index, point_to_voxel, v2p_index, voxel_to_point
+from .point_voxel import initial_voxelize, p2v_index, point_to_voxel, v2p_csr, v2p_index, voxel_to_point
 from .tensor import PointTensor, SparseTensor, cat
 
 __all__ = ["SPVCNN", "Net3DSeg", "BasicConvolutionBlock", "BasicDeconvolutionBlock", "ResidualBlock",
@@ -153,7 +153,7 @@ class SPVCNN(nn.Module):
         return cache, z
 
     @torch.no_grad()
-    def prepare(self, x: SparseTensor) -> None:
+    def prepare(self, x: SparseTensor, backward: bool = True) -> None:
         """Build every index structure the forward AND backward over this batch will need (no feature work): the voxel
         set of each level, the 3^3 map and plan of each level, the 2^3 stride-2 maps with forward and reverse plans, the
         point<->voxel maps of strides 1, 4 and 16.  After this, forwards over the batch only launch feature kernels and
@@ -178,6 +178,8 @@ class SPVCNN(nn.Module):
             if z.idx_query.get(levels[s].s) is None:
                 z.idx_query[levels[s].s], z.weights[levels[s].s] = v2p_index(levels[s], z)
             p2v_index(levels[s], z)
+            if backward:
+                v2p_csr(levels[s], z)
         cache["prepared"] = True
 
     def forward(self, x: SparseTensor) -> torch.Tensor:

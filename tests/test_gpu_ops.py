@@ -376,3 +376,42 @@ def test_voxelize_devoxelize_match_oracle(scans_small):
     assert torch.allclose(got_p.cpu(), want_p.detach(), rtol=RTOL, atol=1e-5)
     gvf = ops.devoxelize_bwd(gp.cuda(), idx8.int().cuda(), w8.cuda(), vox.shape[0])
     assert torch.allclose(gvf.cpu(), vf.grad, rtol=RTOL, atol=1e-5)
+
+
+def test_csr_scatter_kernels_match_atomic_kernels(scans_small):
+    """lt_csr_build + lt_voxelize_csr_fwd / lt_devoxelize_csr_bwd (gathers, ascending entry order) against the atomic
+    scatter kernels and a float64 index_add; CSR structure checked exactly."""
+    from latte_amd import ops
+    g = torch.Generator().manual_seed(5)
+    N, V, C = 20000, 3000, 32
+    idx = torch.randint(-1, V, (N,), generator=g).int()
+    idx[:50] = -1
+    idx[idx == 7] = 8                                       # an empty row
+    perm, off = ops.csr_build(idx.cuda(), V)
+    perm_c, off_c = perm.cpu().long(), off.cpu().long()
+    valid = (idx >= 0).nonzero().squeeze(1)
+    order = valid[torch.sort(idx[valid].long(), stable=True)[1]]
+    assert torch.equal(perm_c[: order.numel()], order)
+    assert torch.equal(off_c, torch.searchsorted(torch.sort(idx[valid].long())[0], torch.arange(V + 1)))
+    feats = torch.randn(N, C, generator=g)
+    counts = ops.spcount(idx.cuda(), V)
+    a = ops.voxelize_fwd(feats.cuda(), idx.cuda(), counts)
+    b = ops.voxelize_csr_fwd(feats.cuda(), (perm, off), V)
+    want = torch.zeros(V, C, dtype=torch.float64).index_add_(0, idx[valid].long(), feats[valid].double())
+    want = want / counts.cpu().clamp(min=1).double().unsqueeze(1)
+    assert rel_err(b.cpu(), want) < 1e-6 and rel_err(a.cpu(), want) < 1e-6
+    assert torch.equal(b, ops.voxelize_csr_fwd(feats.cuda(), (perm, off), V))
+    # devoxelize backward: entries e = 8*point + corner
+    Np = 5000
+    idx8 = torch.randint(-1, V, (Np, 8), generator=g).int()
+    w8 = torch.rand(Np, 8, generator=g)
+    w8[idx8 < 0] = 0.0
+    gout = torch.randn(Np, C, generator=g)
+    csr8 = ops.csr_build(idx8.cuda().view(-1), V)
+    a = ops.devoxelize_bwd(gout.cuda(), idx8.cuda(), w8.cuda(), V)
+    b = ops.devoxelize_csr_bwd(gout.cuda(), csr8, w8.cuda(), V)
+    want = torch.zeros(V, C, dtype=torch.float64)
+    for k in range(8):
+        m = idx8[:, k] >= 0
+        want.index_add_(0, idx8[m, k].long(), (w8[m, k].double().unsqueeze(1) * gout[m].double()))
+    assert rel_err(b.cpu(), want) < 1e-6 and rel_err(a.cpu(), want) < 1e-6
