@@ -29,4 +29,12 @@ n = sum(out["FETCH_SIZE"][k]["dispatches"] for k in conv)
 f = sum(out["FETCH_SIZE"][k]["sum"] for k in conv)
 w = sum(out["WRITE_SIZE"].get(k, {"sum": 0})["sum"] for k in conv)
 print("conv dispatches", n, "FETCH_SIZE/dispatch", f / n, "WRITE_SIZE/dispatch", w / n)
+json.dump({"hbm_bytes_per_launch": round((2 * f / n + w / n) * 1024), "fetch_size_kb_per_launch_raw": f / n,
+           "write_size_kb_per_launch": w / n,
+           "correction": "FETCH_SIZE doubled (gfx950 reports half the bytes of 16-B/lane reads, MI355X_MICROARCH.md #HBM); "
+                         "WRITE_SIZE as reported; KB -> bytes x1024",
+           "dispatches": n,
+           "source": "profiles/$TAG" + "_pmc_hbm.json (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, "
+                     "bench.py --steps 2 --warmup 1)"},
+          open("$R/gpurun_out/prof_$TAG/${TAG}_conv_traffic.json", "w"), indent=1)
 PY
