@@ -8,7 +8,7 @@ from latte_amd import synth
 from latte_amd.spvcnn import Net3DSeg
 from latte_amd.tta_step import LatteStep
 from latte_amd.workload import build_batch, hr_cfg_of
-w = synth.workload("nuscenes_34k_w5")
+w = synth.workload(sys.argv[1] if len(sys.argv) > 1 else "nuscenes_34k_w5")
 torch.manual_seed(1)
 model = Net3DSeg(w["C"], True, "SPVCNN", {"cr": 1.0}).cuda()
 step = LatteStep(model, w["C"], hr_cfg_of(w))
@@ -23,5 +23,5 @@ for _ in range(5):
 torch.cuda.synchronize()
 pr.disable()
 st = pstats.Stats(pr)
-st.sort_stats("cumulative").print_stats(70)
-st.sort_stats("tottime").print_stats(40)
+st.sort_stats("cumulative").print_stats(60)
+st.sort_stats("tottime").print_stats(45)
