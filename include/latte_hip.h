@@ -143,6 +143,12 @@ int lt_spconv_plan_fwd_stats(const float* in, const float* packed, const void* p
 int lt_conv_timer_begin(int32_t capacity);
 int lt_conv_timer_arm(int32_t on); /* pause (0) / resume (1) between begin and end: time a sample of the launches */
 int64_t lt_conv_timer_end(float* ms, int32_t* meta, int64_t capacity);
+/* Diagnostics, no counterpart in the reference (tools/conv_stamps.py): device buffer of cap_words int64 that the
+ * variants 70000 + split-k code of lt_spconv_plan_fwd_v fill with 8 words per wave (s_memtime at entry / after the
+ * prologue / after the main loop / at the end, s_memrealtime at entry / end, slabs | active offsets << 32,
+ * HW_ID | XCC_ID << 32).  Variants 40000/50000/60000 + code read L1-resident weights / rows / both (wrong results on
+ * purpose: they price the memory path).  NULL switches the stamps off. */
+int lt_conv_debug_stamps(void* buf, int64_t cap_words);
 
 /* ------------------------------------------------------------------ BatchNorm(batch stats)+ReLU+residual
  * spnn.BatchNorm + spnn.ReLU + skip add (basic_blocks.py:22-23,56-57,64,69,72,75); TTA forces batch

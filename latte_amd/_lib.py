@@ -47,6 +47,7 @@ SIGNATURES = {
     "lt_conv_timer_begin": (ctypes.c_int, [I32]),
     "lt_conv_timer_arm": (ctypes.c_int, [I32]),
     "lt_conv_timer_end": (I64, [P, P, I64]),
+    "lt_conv_debug_stamps": (ctypes.c_int, [P, I64]),
     "lt_spconv_plan_fwd_stats": (ctypes.c_int, [P, P, P, P, I64, I64, I32, I32, I32, P, P]),
     "lt_bn_finalize_sums": (ctypes.c_int, [P, I64, I32, P, P, P]),
     "lt_spconv_stats_bytes": (I64, [I64, I32]),

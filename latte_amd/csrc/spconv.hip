@@ -20,6 +20,7 @@
 //  * offsets with no neighbour in the 64-row tile are skipped for the whole workgroup, offsets with no neighbour
 //    in a wave's 16-row strip skip that wave's MFMAs (wave-uniform branch).
 #include <hip/hip_ext.h>
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/latte_hip.h"
 
@@ -279,6 +280,8 @@ struct PlanArgs {
   float* partial;                     // optional [row workgroups][2][Cout]: per-workgroup column sums of out and out^2
   int gx;                             // split-k: row workgroups (the grid is 1-D there, see the XCD mapping)
   int swz;                            // split-k: XCD-aware workgroup mapping on
+  int dbg;                            // diagnostics (wrong results): 1 = weights of slab 0 only, 2 = rows 0..15 only, 4 = stamps, 8 / 16 = no A / B loads (split-j)
+  long long* stamps;                  // [workgroup][wave][8]
 };
 
 // events of the armed conv launch timer for the launch being issued (null otherwise): the conv kernels are launched
@@ -286,6 +289,15 @@ struct PlanArgs {
 static hipEvent_t g_conv_ev0 = nullptr, g_conv_ev1 = nullptr;
 #define LT_CONV_LAUNCH(kernel, grid, block, stream, ...) \
   hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, g_conv_ev0, g_conv_ev1, 0, __VA_ARGS__)
+
+// diagnostics: per-wave time stamps of k_spconv_rf (variant bit dbg & 4); buffer set by lt_conv_debug_stamps
+static long long* g_conv_stamps = nullptr;
+static long long g_conv_stamps_cap = 0;
+extern "C" int lt_conv_debug_stamps(void* buf, int64_t cap_words) {
+  g_conv_stamps = (long long*)buf;
+  g_conv_stamps_cap = cap_words;
+  return LT_OK;
+}
 
 typedef __attribute__((address_space(3))) void* lt_lds_ptr;
 typedef __attribute__((address_space(1))) const void* lt_glb_ptr;
@@ -499,6 +511,8 @@ __global__ __launch_bounds__(64 * W) void k_spconv_rf(PlanArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, q = lane >> 4;
+  long long st0 = 0, st1 = 0, st2 = 0, rt0 = 0, tI = 0, tC = 0;
+  if (a.dbg & 4) { st0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
   // workgroups that own at most one plan tile are dispatched heaviest tile first
   // (bx, by) = (row workgroup, column group).  Split-k launches a 1-D grid and maps it XCD-aware: hardware hands
   // consecutive workgroups to the 8 XCDs round-robin, so workgroup L runs on XCD L % 8; the column groups of one row
@@ -571,7 +585,7 @@ __global__ __launch_bounds__(64 * W) void k_spconv_rf(PlanArgs a) {
   // counted s_waitcnt while the current slab's MFMAs run.
   auto issue = [&](int ki, int j, f32x4 (&av)[SR], f32x4 (&bv)[NTW], unsigned int& valid) {
     const int k = __builtin_amdgcn_readfirstlane(s_klist[ki]);
-    const f32x4* wp = wfrag + ((int64_t)k * J + j) * NTt * 64;
+    const f32x4* wp = wfrag + ((a.dbg & 1) ? (int64_t)0 : ((int64_t)k * J + j) * NTt * 64);
 #pragma unroll
     for (int n = 0; n < NTW; ++n) bv[n] = wp[n * 64];
     valid = 0u;
@@ -579,7 +593,8 @@ __global__ __launch_bounds__(64 * W) void k_spconv_rf(PlanArgs a) {
     for (int h = 0; h < SR; ++h) {
       const int src = s_nbr[ki * TMW + 16 * h + r];
       valid |= (src >= 0 ? 1u : 0u) << h;
-      av[h] = *reinterpret_cast<const f32x4*>(in_q + (int64_t)(src < 0 ? 0 : src) * a.Cin + 16 * j);
+      const int srow = (a.dbg & 2) ? r : (src < 0 ? 0 : src);
+      av[h] = *reinterpret_cast<const f32x4*>(in_q + (int64_t)srow * a.Cin + ((a.dbg & 2) ? 0 : 16 * j));
     }
   };
   auto compute = [&](unsigned int act, const f32x4 (&av)[SR], const f32x4 (&bv)[NTW], unsigned int valid) {
@@ -599,6 +614,7 @@ __global__ __launch_bounds__(64 * W) void k_spconv_rf(PlanArgs a) {
   };
   auto act_of = [&](int ki) -> unsigned int { return __builtin_amdgcn_readfirstlane(s_act[ki]); };
 
+  if (a.dbg & 4) st1 = __builtin_amdgcn_s_memtime();
   f32x4 avA[SR], avB[SR], bA[NTW], bB[NTW];
   unsigned int vA = 0u, vB = 0u;
   // this wave's slabs: first, first + step, ... (all of them unless SK)
@@ -618,6 +634,26 @@ __global__ __launch_bounds__(64 * W) void k_spconv_rf(PlanArgs a) {
       }
     };
     issue(ki, jj, avA, bA, vA);
+    if (a.dbg & 4) {
+      // diagnostic loop: the same work with stamps around the issue and compute parts
+      for (int u = 0; u < Uw; u += 2) {
+        long long s0 = __builtin_amdgcn_s_memtime();
+        const unsigned int act0 = act_of(ki);
+        advance();
+        issue(ki, jj, avB, bB, vB);
+        long long s1 = __builtin_amdgcn_s_memtime();
+        compute(act0, avA, bA, vA);
+        long long s2 = __builtin_amdgcn_s_memtime();
+        const unsigned int act1 = (u + 1 < Uw) ? act_of(ki) : 0u;
+        advance();
+        issue(ki, jj, avA, bA, vA);
+        long long s3 = __builtin_amdgcn_s_memtime();
+        compute(act1, avB, bB, vB);
+        long long s4 = __builtin_amdgcn_s_memtime();
+        tI += (s1 - s0) + (s3 - s2);
+        tC += (s2 - s1) + (s4 - s3);
+      }
+    } else
     for (int u = 0; u < Uw; u += 2) {
       const unsigned int act0 = act_of(ki);
       advance();
@@ -630,6 +666,19 @@ __global__ __launch_bounds__(64 * W) void k_spconv_rf(PlanArgs a) {
     }
   }
 
+  if (a.dbg & 4) st2 = __builtin_amdgcn_s_memtime();
+  auto stamp_end = [&]() {
+    if ((a.dbg & 4) && a.stamps && lane == 0) {
+      unsigned hwid, xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      long long* o = a.stamps + ((long long)blockIdx.x * W + wave) * 8;
+      o[0] = st0; o[1] = st1; o[2] = st2; o[3] = __builtin_amdgcn_s_memtime();
+      o[4] = rt0 | (tI << 40); o[5] = __builtin_amdgcn_s_memrealtime() | (tC << 40);
+      o[6] = (long long)U | ((long long)nact << 32);
+      o[7] = (long long)hwid | ((long long)xcc << 32);
+    }
+  };
   if constexpr (SK) {
     // strip h is finished by wave h % W: partial accumulators of the others through LDS, added in wave order; the
     // finishing wave stores the rows and keeps their column sums
@@ -691,6 +740,7 @@ __global__ __launch_bounds__(64 * W) void k_spconv_rf(PlanArgs a) {
         }
       }
     }
+    stamp_end();
     return;
   }
 
@@ -752,6 +802,7 @@ static void launch_sk_one(const PlanArgs& a, hipStream_t stream) {
   b.gx = (int)gx;
   const unsigned gy = (unsigned)(a.Cout / (16 * NTW));
   const unsigned total = ((gx + 7) / 8) * 8 * gy;
+  if (b.stamps && g_conv_stamps_cap < (long long)total * W * 8) b.stamps = nullptr;
   LT_CONV_LAUNCH((k_spconv_rf<SR, NTW, W, true>), dim3(total), dim3(64 * W), stream, b);
 }
 
@@ -802,6 +853,333 @@ static int launch_rf(const PlanArgs& a, int sr, hipStream_t stream) {
   else if (sr == 2) LT_RF(2);
   else LT_RF(1);
 #undef LT_RF
+  LT_LAUNCH_CHECK();
+  return LT_OK;
+}
+
+// =====================================================================================================
+// Split-j kernel: the split-k kernel above with the slab list cut along the channel groups instead of flat.
+//
+// Same decomposition (W waves own the same SR strips x NTW column tiles, partial sums added in wave order), but wave w
+// takes the channel groups j = w, w+W, ... of EVERY active offset (needs J % W == 0).  For such shapes the assignment and
+// the order of every partial sum are those of k_spconv_rf<.., SK> -> bitwise equal results.  What changes is the cost of
+// getting from one slab to the next, which the in-kernel stamps (tools/conv_stamps.py) showed to be ~2000 wave-cycles
+// per slab against 1024 MFMA-pipe cycles in the flat loop (three dependent LDS round trips, ~45 scalar and ~25 vector
+// instructions of index arithmetic per slab):
+//  * everything that depends on the offset only (kernel offset k, strip activity, the SR gathered row pointers) is
+//    computed once per offset and kept in registers; inside an offset the next slab is a constant stride away for both
+//    operands (A: +16*W floats in the row, B: +W*NTt KiB in the packed image);
+//  * the per-offset table (k, activity) lives in one VGPR (lane ki = entry ki) and is read with v_readlane, not LDS;
+//  * the neighbour rows of the NEXT offset are read from LDS one offset ahead;
+//  * operands come through raw buffer loads (scalar slab offsets); a missing neighbour is an out-of-range offset that
+//    the hardware answers with zeros, instead of a v_cndmask at compute time.
+
+template <int SR, int NTW, int W>
+__global__ __launch_bounds__(64 * W) void k_spconv_sj(PlanArgs a) {
+  constexpr int PARTS = SR >= 4 ? 1 : 4 / SR;  // workgroups per plan tile (SR < 4: a workgroup owns SR of its 4 strips)
+  constexpr int TMW = 16 * SR;                 // rows per workgroup (SR in {1,2,4}: at most one plan tile)
+  __shared__ int s_nbr[LT_KMAX * TMW];  // [nact][TMW] neighbour rows of the active offsets
+  __shared__ int s_rows[TMW];
+  __shared__ int s_klist[LT_KMAX];
+  __shared__ unsigned int s_act[LT_KMAX];  // per active offset: bit h = strip h has a neighbour
+  __shared__ int s_nact;
+  __shared__ f32x4 s_red[W * NTW * 64];  // [W][NTW][64] partial accumulators of one strip
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  long long st0 = 0, st1 = 0, st2 = 0, rt0 = 0;
+  if (a.dbg & 4) { st0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
+  // XCD-aware mapping of the 1-D grid (see k_spconv_rf)
+  const unsigned gy = a.Cout / (16 * NTW);
+  unsigned bx, by;
+  if (a.swz) {
+    const unsigned L = blockIdx.x, i = L >> 3;
+    bx = (i / gy) * 8 + (L & 7);
+    by = i % gy;
+  } else {
+    bx = blockIdx.x % a.gx;
+    by = blockIdx.x / a.gx;
+  }
+  if (bx >= (unsigned)a.gx || by >= gy) return;  // padding of the 1-D grid
+  const int64_t tile0 = (int64_t)a.torder[bx / PARTS];  // heaviest tile first
+  const int s0 = PARTS == 1 ? 0 : (int)(bx % PARTS) * SR;  // first strip inside the plan tile
+  const int J = a.Cin / 16, NTt = a.Cout / 16;
+  const int JW = J / W;  // slabs per offset and wave (host: J % W == 0)
+  const int nt0 = by * NTW;
+
+  if (wave == 0) {
+    unsigned int act = 0u;
+    unsigned long long m = 0ull;
+    if (lane < a.K) m = a.tmask[tile0 * a.K + lane];
+#pragma unroll
+    for (int st = 0; st < SR; ++st)
+      if ((m >> (16 * (s0 + st))) & 0xFFFFull) act |= 1u << st;
+    const unsigned long long bal = __ballot(act != 0u);
+    if (act != 0u) {
+      const int pos = __popcll(bal & ((1ull << lane) - 1ull));
+      s_klist[pos] = lane;
+      s_act[pos] = act;
+    }
+    if (lane == 0) s_nact = __popcll(bal);
+  }
+  for (int i = tid; i < TMW; i += 64 * W) {
+    const int64_t slot = tile0 * LT_TM + 16 * s0 + i;
+    s_rows[i] = slot < a.Vout ? a.order[slot] : -1;
+  }
+  __syncthreads();
+  const int nact = s_nact;
+  for (int e = tid; e < nact * TMW; e += 64 * W) {
+    const int ki = e / TMW, i = e - ki * TMW;
+    int v = a.tnbr[(tile0 * a.K + s_klist[ki]) * LT_TM + 16 * s0 + i];
+    if (v >= a.Vin) v = -1;  // defensive: never gather out of bounds
+    s_nbr[e] = v;
+  }
+  __syncthreads();
+  // per-offset table in registers: lane ki holds entry ki
+  const int kl_v = lane < nact ? s_klist[lane] : 0;
+  const unsigned int act_v = lane < nact ? s_act[lane] : 0u;
+
+  f32x4 acc[SR][NTW];
+#pragma unroll
+  for (int h = 0; h < SR; ++h)
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) acc[h][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // Operands are read with raw buffer loads: a 32-bit per-lane offset that changes once per offset k, a scalar offset that
+  // moves from slab to slab, no vector address arithmetic in the loop.  A missing neighbour gets a per-lane offset past
+  // the end of the buffer: the hardware range check returns zeros for it and no memory is touched.
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0,
+                                                                        (int)((int64_t)a.Vin * a.Cin * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.packed), 0,
+                                                                        (int)((int64_t)a.K * a.Cin * a.Cout * 4), 0x00020000);
+  const int lane_a = (4 * q + 16 * wave) * 4;             // bytes into a gathered row: this wave's first channel group
+  const int lane_b = lane * 16;                           // bytes into a packed 1-KiB fragment
+  const int row_bytes = a.Cin * 4;
+  const int wstep = W * NTt * 1024;                       // bytes from channel group j to j + W in the packed image
+  const int wkstep = J * NTt * 1024;                      // ... from offset k to k + 1
+  const int wbase = (wave * NTt + nt0) * 1024;
+  if (a.dbg & 4) st1 = __builtin_amdgcn_s_memtime();
+
+  const int Uw = nact * JW;  // slabs of this wave
+  if (Uw > 0) {
+    // state of the offset being issued
+    int voff[SR];            // per-lane byte offset of the gathered row (past the end: no neighbour)
+    int soff_b;              // scalar byte offset of the packed fragment of (k, j)
+    int soff_a = 0;          // scalar byte offset inside the row: 64 * W * jj
+    unsigned int act_cur;
+    int srcn[SR];  // neighbour rows of the next offset (read from LDS one offset ahead)
+    int ki = 0, jj = 0;
+    auto install = [&]() {  // ki < nact: make offset ki current; otherwise: past the end (no work, loads return zeros)
+      if (ki < nact) {
+        const int k = __builtin_amdgcn_readlane(kl_v, ki);
+        act_cur = (unsigned int)__builtin_amdgcn_readlane((int)act_v, ki);
+        soff_b = wbase + k * wkstep;
+#pragma unroll
+        for (int h = 0; h < SR; ++h) voff[h] = srcn[h] >= 0 ? srcn[h] * row_bytes + lane_a : 0x7FFFF000;
+        const int kn = ki + 1 < nact ? ki + 1 : ki;
+#pragma unroll
+        for (int h = 0; h < SR; ++h) srcn[h] = s_nbr[kn * TMW + 16 * h + r];
+      } else {
+        act_cur = 0u;
+#pragma unroll
+        for (int h = 0; h < SR; ++h) voff[h] = 0x7FFFF000;
+      }
+    };
+#pragma unroll
+    for (int h = 0; h < SR; ++h) srcn[h] = s_nbr[16 * h + r];
+    install();
+    // addresses of the slab to load next, captured before the state moves on
+    int nvoff[SR], nsoff_a, nsoff_b;
+    unsigned int nact_bits;
+    auto capture_and_advance = [&]() {
+      nact_bits = act_cur;
+      nsoff_a = soff_a;
+      nsoff_b = soff_b;
+#pragma unroll
+      for (int h = 0; h < SR; ++h) nvoff[h] = voff[h];
+      if (++jj == JW) {  // wave-uniform: next offset
+        jj = 0;
+        soff_a = 0;
+        ++ki;
+        install();
+      } else {
+        soff_a += 64 * W;
+        soff_b += wstep;
+      }
+    };
+    auto load_one = [&](int ld, f32x4 (&av2)[SR], f32x4 (&bv2)[NTW]) {
+      // order: strip 0's rows, the weights, the other strips' rows -- what the next slab multiplies first comes first
+      if (ld == 0) {
+        av2[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, nvoff[0], nsoff_a, 0));
+      } else if (ld <= NTW) {
+        bv2[ld - 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, lane_b + (ld - 1) * 1024, nsoff_b, 0));
+      } else if (ld < NTW + SR) {
+        av2[ld - NTW] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, nvoff[ld - NTW], nsoff_a, 0));
+      }
+    };
+    // The operand loads of the next slab are spread over the MFMA groups of the current one (one load after every NTW
+    // MFMAs) instead of being issued as a burst: a vector-memory instruction costs ~60+ cycles of issue, a burst of
+    // SR+NTW of them from every wave backs the address path up and the MFMA pipe idles meanwhile (282 -> 230 us at
+    // stride 8, C=256).
+    auto compute_and_load = [&](unsigned int act, const f32x4 (&av)[SR], const f32x4 (&bv)[NTW], f32x4 (&av2)[SR],
+                                f32x4 (&bv2)[NTW]) {
+      constexpr int NL = NTW + SR;               // loads of a slab
+      constexpr int PER = (NL + SR - 1) / SR;    // ... issued beside one strip's MFMAs
+#pragma unroll
+      for (int h = 0; h < SR; ++h) {
+        const bool on = (act >> h) & 1u;  // wave-uniform: the strip has a neighbour at this offset
+        if (!on) {
+#pragma unroll
+          for (int e = 0; e < PER; ++e) load_one(h * PER + e, av2, bv2);
+        }
+        if (on) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int n = 0; n < NTW; ++n)
+              acc[h][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[h][t], bv[n][t], acc[h][n], 0, 0, 0);
+            if (t < PER) load_one(h * PER + t, av2, bv2);
+          }
+#pragma unroll
+          for (int e = 4; e < PER; ++e) load_one(h * PER + e, av2, bv2);
+          // keep the loads where they were written: one after every NTW MFMAs
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            __builtin_amdgcn_sched_group_barrier(0x008, NTW, 0);
+            if (t < PER && h * PER + t < NL) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          }
+        }
+      }
+    };
+    f32x4 avA[SR], avB[SR], bA[NTW], bB[NTW];
+    unsigned int actA = 0u, actB = 0u;
+    // first slab: plain burst
+    capture_and_advance();
+    actA = nact_bits;
+#pragma unroll
+    for (int e = 0; e < NTW + SR; ++e) load_one(e, avA, bA);
+    for (int u = 0; u < Uw; u += 2) {
+      capture_and_advance();
+      actB = nact_bits;
+      compute_and_load(actA, avA, bA, avB, bB);
+      capture_and_advance();
+      actA = nact_bits;
+      compute_and_load(actB, avB, bB, avA, bA);
+    }
+  }
+  if (a.dbg & 4) st2 = __builtin_amdgcn_s_memtime();
+
+  // strip h is finished by wave h % W: partial accumulators of the others through LDS, added in wave order; the
+  // finishing wave stores the rows and keeps their column sums
+  float s1[NTW], s2[NTW];
+#pragma unroll
+  for (int n = 0; n < NTW; ++n) s1[n] = s2[n] = 0.f;
+#pragma unroll
+  for (int h = 0; h < SR; ++h) {
+    const int owner = h % W;
+    f32x4* red = s_red;
+    if (h > 0) __syncthreads();  // the previous strip's partials have been read
+    if (wave != owner) {
+#pragma unroll
+      for (int n = 0; n < NTW; ++n) red[(wave * NTW + n) * 64 + lane] = acc[h][n];
+    }
+    __syncthreads();
+    if (wave == owner) {
+#pragma unroll
+      for (int n = 0; n < NTW; ++n) {
+        f32x4 sum = owner == 0 ? acc[h][n] : red[n * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < W; ++w) {
+          const f32x4 v = w == owner ? acc[h][n] : red[(w * NTW + n) * 64 + lane];
+          sum[0] += v[0]; sum[1] += v[1]; sum[2] += v[2]; sum[3] += v[3];
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int row = s_rows[16 * h + 4 * q + reg];
+          if (row >= 0) a.out[(int64_t)row * a.Cout + 16 * (nt0 + n) + r] = sum[reg];
+          s1[n] += sum[reg];
+          s2[n] += sum[reg] * sum[reg];
+        }
+      }
+    }
+  }
+  if (a.partial) {
+    // column sums of the workgroup's rows: per wave over its strips, then over the waves in wave order through LDS
+    float* redf = reinterpret_cast<float*>(s_red);  // [W][NTW][2][16]
+    __syncthreads();                                // the last strip's partial accumulators have been read
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) {
+      float t1 = s1[n], t2 = s2[n];
+      t1 += __shfl_xor(t1, 16, 64); t2 += __shfl_xor(t2, 16, 64);
+      t1 += __shfl_xor(t1, 32, 64); t2 += __shfl_xor(t2, 32, 64);
+      if (q == 0) {
+        redf[((wave * NTW + n) * 2 + 0) * 16 + r] = t1;
+        redf[((wave * NTW + n) * 2 + 1) * 16 + r] = t2;
+      }
+    }
+    __syncthreads();
+    if (wave == 0 && lane < 32) {
+      const int which = lane >> 4;
+#pragma unroll
+      for (int n = 0; n < NTW; ++n) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < W; ++w) t += redf[((w * NTW + n) * 2 + which) * 16 + r];
+        a.partial[((int64_t)bx * 2 + which) * a.Cout + 16 * (nt0 + n) + r] = t;
+      }
+    }
+  }
+  if ((a.dbg & 4) && a.stamps && lane == 0) {
+    unsigned hwid, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    long long* o = a.stamps + ((long long)blockIdx.x * W + wave) * 8;
+    o[0] = st0; o[1] = st1; o[2] = st2; o[3] = __builtin_amdgcn_s_memtime();
+    o[4] = rt0; o[5] = __builtin_amdgcn_s_memrealtime();
+    o[6] = (long long)(nact * J) | ((long long)nact << 32);
+    o[7] = (long long)hwid | ((long long)xcc << 32);
+  }
+}
+
+template <int SR, int NTW, int W>
+static void launch_sj_one(const PlanArgs& a, hipStream_t stream) {
+  const unsigned gx = (unsigned)(((a.Vout + LT_TM - 1) / LT_TM) * (SR >= 4 ? 1 : 4 / SR));
+  PlanArgs b = a;
+  b.gx = (int)gx;
+  const unsigned gy = (unsigned)(a.Cout / (16 * NTW));
+  const unsigned total = ((gx + 7) / 8) * 8 * gy;
+  if (b.stamps && g_conv_stamps_cap < (long long)total * W * 8) b.stamps = nullptr;
+  LT_CONV_LAUNCH((k_spconv_sj<SR, NTW, W>), dim3(total), dim3(64 * W), stream, b);
+}
+
+// split-j launch: sr in {1,2,4}, ntw in {2,3,4}, w in {2,3,4,6,8}; needs (Cin/16) % w == 0 and Cin <= LT_ZERO_ROW
+static bool sj_supported(int Cin, int sr, int ntw, int w) {
+  return (sr == 1 || sr == 2 || sr == 4) && (ntw == 2 || ntw == 3 || ntw == 4) &&
+         (w == 2 || w == 3 || w == 4 || w == 6 || w == 8) && (Cin / 16) % w == 0;
+}
+static int launch_sj(const PlanArgs& a, int sr, int ntw, int w, hipStream_t stream) {
+#define LT_SJ_W(SRv, NTWv)                                          \
+  do {                                                              \
+    switch (w) {                                                    \
+      case 8: launch_sj_one<SRv, NTWv, 8>(a, stream); break;        \
+      case 6: launch_sj_one<SRv, NTWv, 6>(a, stream); break;        \
+      case 4: launch_sj_one<SRv, NTWv, 4>(a, stream); break;        \
+      case 3: launch_sj_one<SRv, NTWv, 3>(a, stream); break;        \
+      default: launch_sj_one<SRv, NTWv, 2>(a, stream); break;       \
+    }                                                               \
+  } while (0)
+#define LT_SJ_NTW(SRv)                                              \
+  do {                                                              \
+    if (ntw == 4) LT_SJ_W(SRv, 4);                                  \
+    else if (ntw == 3) LT_SJ_W(SRv, 3);                             \
+    else LT_SJ_W(SRv, 2);                                           \
+  } while (0)
+  if (sr == 4) LT_SJ_NTW(4);
+  else if (sr == 2) LT_SJ_NTW(2);
+  else LT_SJ_NTW(1);
+#undef LT_SJ_NTW
+#undef LT_SJ_W
   LT_LAUNCH_CHECK();
   return LT_OK;
 }
@@ -871,21 +1249,27 @@ extern "C" int64_t lt_conv_timer_end(float* ms, int32_t* meta, int64_t capacity)
   return n;
 }
 
-// Default kernel shape (measured on every level / width of the U-Net, tools/conv_bench.py + tools/cb_sk.sh):
-// the split-k flavour with 4 column tiles per wave (3 for Cout = 48, 96, ...) and 32-row workgroups of 4 waves; 8 waves
-// when that leaves fewer than 6000 waves, and 16-row workgroups below 4000 (the coarsest levels).
+// Default kernel shape (measured on every level / width of the U-Net: tools/conv_bench.py + tools/cb_sj.sh):
+// 16-row workgroups (SR = 1: the finest work items -> the shortest tail, and no strip of a workgroup is ever inactive),
+// 4 column tiles per wave (3 for Cout = 48, 96, ...), and the channel groups of an offset split over W = 2 waves, or 4
+// when 2 would leave fewer than 7000 waves or the input is 256 channels or wider.  The split-j kernel runs it whenever W
+// divides Cin/16; other widths take the flat split-k loop with the same shape.
 struct LtConvShape {
   int sr, ntw, w;
+  bool sj;
 };
-static LtConvShape conv_default_shape(int64_t Vout, int Cout) {
-  const int ntt = Cout / 16;
+static bool sj_supported(int Cin, int sr, int ntw, int w);
+static LtConvShape conv_default_shape(int64_t Vin, int64_t Vout, int Cin, int Cout, int K) {
+  const int ntt = Cout / 16, J = Cin / 16;
   LtConvShape s;
   s.ntw = ntt % 4 == 0 ? 4 : ntt % 3 == 0 ? 3 : ntt % 2 == 0 ? 2 : 1;
-  s.sr = 2;
-  s.w = 4;
-  const int64_t waves = ((Vout + 16 * s.sr - 1) / (16 * s.sr)) * (ntt / s.ntw) * s.w;
-  if (waves < 4000) { s.sr = 1; s.w = 8; }
-  else if (waves < 6000) s.w = 8;
+  s.sr = 1;
+  const int64_t waves2 = ((Vout + 15) / 16) * (ntt / s.ntw) * 2;
+  s.w = (waves2 >= 7000 && J < 16) ? 2 : 4;
+  if (J % s.w != 0 && J % 2 == 0) s.w = 2;
+  s.sj = s.ntw >= 2 && sj_supported(Cin, s.sr, s.ntw, s.w) && Vin * Cin * 4 < 0x7FFFF000ll &&
+         (int64_t)K * Cin * Cout * 4 < 0x7FFFF000ll;
+  if (!s.sj && s.w != 2 && s.w != 4 && s.w != 8) s.w = 4;
   return s;
 }
 static int64_t rf_grid_x(int64_t Vout, int sr) {
@@ -895,8 +1279,7 @@ static int64_t rf_grid_x(int64_t Vout, int sr) {
 
 extern "C" int64_t lt_spconv_stat_blocks(int64_t Vout, int32_t Cout) {
   if (Vout <= 0 || Cout < 16) return 0;
-  const LtConvShape s = conv_default_shape(Vout, Cout);
-  return rf_grid_x(Vout, s.sr);
+  return rf_grid_x(Vout, 1);  // every default shape has 16-row workgroups
 }
 
 extern "C" int64_t lt_spconv_stats_bytes(int64_t Vout, int32_t Cout) {
@@ -932,13 +1315,15 @@ static int spconv_plan_impl(const float* in, const float* packed, const void* pl
   LT_REQUIRE(packed && plan && out && (Vin == 0 || in), LT_ERR_ARG, "lt_spconv_plan_fwd: null pointer");
   LT_REQUIRE(((uintptr_t)plan & 15) == 0, LT_ERR_ARG, "lt_spconv_plan_fwd: plan must be 16-byte aligned");
   LtPlanView pv = lt_plan_view(const_cast<void*>(plan), K, Vout);
-  PlanArgs a{in, packed, pv.tnbr, pv.tmask, pv.order, pv.torder, out, (int)Vin, (int)Vout, Cin, Cout, K, partial, 0, 1};
+  PlanArgs a{in, packed, pv.tnbr, pv.tmask, pv.order, pv.torder, out, (int)Vin, (int)Vout, Cin, Cout, K, partial, 0, 1, 0, nullptr};
   LtConvTimerScope timed(stream, Cin, Cout, K, Vout);
   const int ntt = Cout / 16;
   LT_REQUIRE(!(partial && variant != 0), LT_ERR_ARG, "lt_spconv_plan_fwd: statistics need the default variant");
   if (variant == 0) {
-    const LtConvShape sh = conv_default_shape(Vout, Cout);
-    return launch_sk(a, sh.sr, sh.ntw, sh.w, stream);
+    const LtConvShape sh = conv_default_shape(Vin, Vout, Cin, Cout, K);
+    static const bool no_sj = getenv("LT_CONV_NO_SPLITJ") != nullptr;  // A/B measurements: the flat split-k loop
+    if (sh.sj && !no_sj) return launch_sj(a, sh.sr, sh.ntw, sh.w, stream);
+    return launch_sk(a, sh.sr, sh.ntw, sh.w == 2 || sh.w == 4 || sh.w == 8 ? sh.w : 4, stream);
   }
   int sr = 1, ntw = 1;
   if (variant == 1) {  // the LDS-DMA staged kernel
@@ -949,10 +1334,25 @@ static int spconv_plan_impl(const float* in, const float* packed, const void* pl
     if (ntt % 2 == 0) return launch_plan<2, 8>(a, stream);
     return launch_plan<1, 8>(a, stream);
   }
+  if (variant >= 40000) {  // 40000/50000/60000 + split-k code: diagnostics with L1-resident weights / rows / both
+    a.dbg = variant / 10000 - 3;
+    variant %= 10000;
+    if (a.dbg & 4) a.stamps = g_conv_stamps;
+  }
   if (variant >= 10000) {  // 10000 + split-k code: the same without the XCD-aware workgroup mapping (A/B measurements)
     a.swz = 0;
     variant -= 10000;
     LT_REQUIRE(variant >= 1000, LT_ERR_ARG, "lt_spconv_plan_fwd_v: unknown variant %d", variant + 10000);
+  }
+  if (variant >= 2000 && variant < 3000) {  // split-j: 2000 + 100*SR + 10*NTW + W
+    const int v = variant - 2000;
+    sr = v / 100;
+    ntw = (v / 10) % 10;
+    const int w = v % 10;
+    LT_REQUIRE(sj_supported(Cin, sr, ntw, w) && ntt % ntw == 0 && Vin * Cin * 4 < 0x7FFFF000ll &&
+                   (int64_t)K * Cin * Cout * 4 < 0x7FFFF000ll, LT_ERR_ARG,
+               "lt_spconv_plan_fwd_v: bad variant %d for Cin=%d Cout=%d", variant, Cin, Cout);
+    return launch_sj(a, sr, ntw, w, stream);
   }
   if (variant >= 1000) {  // split-k: 1000 + 100*SR + 10*NTW + W
     const int v = variant - 1000;
