@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblatte_hip.so")
+# LATTE_HIP_LIB: another build of the same library (A/B measurements of kernel changes on one GPU box)
+LIB_PATH = os.environ.get("LATTE_HIP_LIB") or os.path.join(_HERE, "liblatte_hip.so")
 
 P = ctypes.c_void_p
 I64 = ctypes.c_int64
