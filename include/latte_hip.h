@@ -161,14 +161,16 @@ int lt_bn_finalize_sums(void* stats_ws, int64_t V, int32_t C, float* mean, float
 int lt_bn_apply(const float* x, const float* mean, const float* var, const float* gamma, const float* beta,
                 float eps, const float* residual, int32_t relu, float* y, int64_t V, int32_t C,
                 lt_stream_t stream);
-/* g = dy * (y>0 if relu);  sum_g[c] = sum g;  sum_gx[c] = sum g*xhat */
+/* g = dy * mask;  sum_g[c] = sum g;  sum_gx[c] = sum g*xhat.  relu: 0 = no ReLU (mask = 1); 1 = mask = (y > 0), y read;
+ * 2 = the forward added no residual: mask = (gamma*xhat + beta > 0) rebuilt from x with the forward's own expression
+ * (bit-identical to y > 0), y is not read (may be NULL), gamma / beta are needed (NULL allowed for relu 0 / 1). */
 int lt_bn_bwd_reduce(const float* dy, const float* x, const float* y, const float* mean, const float* var,
-                     float eps, int32_t relu, int64_t V, int32_t C, void* ws, int64_t ws_bytes, float* sum_g,
-                     float* sum_gx, lt_stream_t stream);
-/* dx = gamma*rstd*(g - sum_g/V - xhat*sum_gx/V); dres = g (optional) */
+                     const float* gamma, const float* beta, float eps, int32_t relu, int64_t V, int32_t C, void* ws,
+                     int64_t ws_bytes, float* sum_g, float* sum_gx, lt_stream_t stream);
+/* dx = gamma*rstd*(g - sum_g/V - xhat*sum_gx/V); dres = g (optional); relu and beta as in lt_bn_bwd_reduce */
 int lt_bn_bwd_apply(const float* dy, const float* x, const float* y, const float* mean, const float* var,
-                    const float* gamma, float eps, int32_t relu, const float* sum_g, const float* sum_gx,
-                    float* dx, float* dres, int64_t V, int32_t C, lt_stream_t stream);
+                    const float* gamma, const float* beta, float eps, int32_t relu, const float* sum_g,
+                    const float* sum_gx, float* dx, float* dres, int64_t V, int32_t C, lt_stream_t stream);
 
 /* ------------------------------------------------------------------ conv -> BN [+ residual] [+ ReLU] in one call
  * The block pattern of latte/models/basic_blocks.py:13-76 (Conv3d, BatchNorm, ReLU / residual add) as ONE host call:
@@ -182,7 +184,8 @@ int lt_conv_bn_fwd(const float* in, const float* packed, const void* plan, int64
                    int32_t relu, void* ws, int64_t ws_bytes, float* conv_out, float* y, float* mean, float* var,
                    lt_stream_t stream);
 int lt_conv_bn_bwd(const float* dy, const float* conv_out, const float* y, const float* mean, const float* var,
-                   const float* gamma, float eps, int32_t relu, int64_t Vout, int32_t Cout, void* ws, int64_t ws_bytes,
+                   const float* gamma, const float* beta, float eps, int32_t relu, int64_t Vout, int32_t Cout, void* ws,
+                   int64_t ws_bytes,
                    float* dgamma, float* dbeta, float* dres, float* dconv, const float* packed_bwd, const void* plan_bwd,
                    int64_t Vin, int32_t Cin, int32_t K, float* din, lt_stream_t stream);
 

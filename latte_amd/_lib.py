@@ -54,7 +54,7 @@ SIGNATURES = {
     "lt_spconv_stats_bytes": (I64, [I64, I32]),
     "lt_conv_bn_workspace_bytes": (I64, [I64, I32]),
     "lt_conv_bn_fwd": (ctypes.c_int, [P, P, P, I64, I64, I32, I32, I32, P, P, F32, P, I32, P, I64, P, P, P, P, P]),
-    "lt_conv_bn_bwd": (ctypes.c_int, [P, P, P, P, P, P, F32, I32, I64, I32, P, I64, P, P, P, P, P, P, I64, I32, I32, P,
+    "lt_conv_bn_bwd": (ctypes.c_int, [P, P, P, P, P, P, P, F32, I32, I64, I32, P, I64, P, P, P, P, P, P, I64, I32, I32, P,
                                        P]),
     "lt_spconv_packed_floats": (I64, [I32, I32, I32]),
     "lt_spconv_pack_weights": (ctypes.c_int, [P, I32, I32, I32, I32, P, P]),
@@ -62,8 +62,8 @@ SIGNATURES = {
     "lt_bn_workspace_bytes": (I64, [I64, I32]),
     "lt_bn_stats": (ctypes.c_int, [P, I64, I32, P, I64, P, P, P]),
     "lt_bn_apply": (ctypes.c_int, [P, P, P, P, P, F32, P, I32, P, I64, I32, P]),
-    "lt_bn_bwd_reduce": (ctypes.c_int, [P, P, P, P, P, F32, I32, I64, I32, P, I64, P, P, P]),
-    "lt_bn_bwd_apply": (ctypes.c_int, [P, P, P, P, P, P, F32, I32, P, P, P, P, I64, I32, P]),
+    "lt_bn_bwd_reduce": (ctypes.c_int, [P, P, P, P, P, P, P, F32, I32, I64, I32, P, I64, P, P, P]),
+    "lt_bn_bwd_apply": (ctypes.c_int, [P, P, P, P, P, P, P, F32, I32, P, P, P, P, I64, I32, P]),
     "lt_voxelize_fwd": (ctypes.c_int, [P, P, P, P, I64, I32, I64, P]),
     "lt_voxelize_bwd": (ctypes.c_int, [P, P, P, P, I64, I32, I64, P]),
     "lt_calc_ti_weights": (ctypes.c_int, [P, P, I64, I32, P, P]),

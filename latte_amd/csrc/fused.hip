@@ -24,7 +24,8 @@ extern "C" int lt_conv_bn_fwd(const float* in, const float* packed, const void* 
 }
 
 extern "C" int lt_conv_bn_bwd(const float* dy, const float* conv_out, const float* y, const float* mean, const float* var,
-                              const float* gamma, float eps, int32_t relu, int64_t Vout, int32_t Cout, void* ws,
+                              const float* gamma, const float* beta, float eps, int32_t relu, int64_t Vout, int32_t Cout,
+                              void* ws,
                               int64_t ws_bytes, float* dgamma, float* dbeta, float* dres, float* dconv,
                               const float* packed_bwd, const void* plan_bwd, int64_t Vin, int32_t Cin, int32_t K, float* din,
                               hipStream_t stream) {
@@ -32,10 +33,12 @@ extern "C" int lt_conv_bn_bwd(const float* dy, const float* conv_out, const floa
   LT_REQUIRE(dgamma && dbeta, LT_ERR_ARG, "lt_conv_bn_bwd: null pointer");
   LT_REQUIRE(!din || (dconv && packed_bwd && plan_bwd), LT_ERR_ARG, "lt_conv_bn_bwd: din needs dconv, packed_bwd and plan_bwd");
   // sum_g = dbeta, sum_gx = dgamma
-  int rc = lt_bn_bwd_reduce(dy, conv_out, y, mean, var, eps, relu, Vout, Cout, ws, ws_bytes, dbeta, dgamma, stream);
+  int rc = lt_bn_bwd_reduce(dy, conv_out, y, mean, var, gamma, beta, eps, relu, Vout, Cout, ws, ws_bytes, dbeta, dgamma,
+                            stream);
   if (rc) return rc;
   if (dconv || dres) {
-    rc = lt_bn_bwd_apply(dy, conv_out, y, mean, var, gamma, eps, relu, dbeta, dgamma, dconv, dres, Vout, Cout, stream);
+    rc = lt_bn_bwd_apply(dy, conv_out, y, mean, var, gamma, beta, eps, relu, dbeta, dgamma, dconv, dres, Vout, Cout,
+                         stream);
     if (rc) return rc;
   }
   if (din) {

@@ -38,13 +38,21 @@ struct StatsOp {
   }
 };
 
+// the BatchNorm output of one element, the same expression (and rounding) wherever it is evaluated: the forward apply,
+// and the backward kernels that rebuild the ReLU mask from x instead of reading y (relu == 2: no residual was added)
+__device__ __forceinline__ float bn_affine(float v, float m, float vr, float g, float b, float eps) {
+  return __fmaf_rn((v - m) * (1.0f / sqrtf(vr + eps)), g, b);
+}
+
 struct BwdOp {
   const float* dy;
   const float* x;
-  const float* y;  // may be null (no relu)
+  const float* y;  // ReLU mask from y; null: no ReLU, or (gamma != null) mask rebuilt from x
   const float* mean;
   const float* var;
   float eps;
+  const float* gamma;  // non-null: rebuild the ReLU mask  gamma * xhat + beta > 0
+  const float* beta;
   __device__ void operator()(int64_t row, int cg, int C, float4& a, float4& b) const {
     float4 g = reinterpret_cast<const float4*>(dy + row * C)[cg];
     if (y) {
@@ -55,6 +63,14 @@ struct BwdOp {
     const float4 v = reinterpret_cast<const float4*>(x + row * C)[cg];
     const float4 m = reinterpret_cast<const float4*>(mean)[cg];
     const float4 vr = reinterpret_cast<const float4*>(var)[cg];
+    if (gamma) {
+      const float4 gm = reinterpret_cast<const float4*>(gamma)[cg];
+      const float4 bt = reinterpret_cast<const float4*>(beta)[cg];
+      g.x = bn_affine(v.x, m.x, vr.x, gm.x, bt.x, eps) > 0.f ? g.x : 0.f;
+      g.y = bn_affine(v.y, m.y, vr.y, gm.y, bt.y, eps) > 0.f ? g.y : 0.f;
+      g.z = bn_affine(v.z, m.z, vr.z, gm.z, bt.z, eps) > 0.f ? g.z : 0.f;
+      g.w = bn_affine(v.w, m.w, vr.w, gm.w, bt.w, eps) > 0.f ? g.w : 0.f;
+    }
     a.x += g.x; a.y += g.y; a.z += g.z; a.w += g.w;
     b.x += g.x * ((v.x - m.x) * (1.0f / sqrtf(vr.x + eps)));
     b.y += g.y * ((v.y - m.y) * (1.0f / sqrtf(vr.y + eps)));
@@ -236,10 +252,10 @@ __global__ void k_bn_apply(const float* __restrict__ x, const float* __restrict_
     const float4 g = reinterpret_cast<const float4*>(gamma)[cg];
     const float4 b = reinterpret_cast<const float4*>(beta)[cg];
     float4 o;
-    o.x = (v.x - m.x) * (1.0f / sqrtf(vr.x + eps)) * g.x + b.x;
-    o.y = (v.y - m.y) * (1.0f / sqrtf(vr.y + eps)) * g.y + b.y;
-    o.z = (v.z - m.z) * (1.0f / sqrtf(vr.z + eps)) * g.z + b.z;
-    o.w = (v.w - m.w) * (1.0f / sqrtf(vr.w + eps)) * g.w + b.w;
+    o.x = bn_affine(v.x, m.x, vr.x, g.x, b.x, eps);
+    o.y = bn_affine(v.y, m.y, vr.y, g.y, b.y, eps);
+    o.z = bn_affine(v.z, m.z, vr.z, g.z, b.z, eps);
+    o.w = bn_affine(v.w, m.w, vr.w, g.w, b.w, eps);
     if (res) {
       const float4 rr = reinterpret_cast<const float4*>(res)[e];
       o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
@@ -265,15 +281,17 @@ extern "C" int lt_bn_apply(const float* x, const float* mean, const float* var, 
 }
 
 extern "C" int lt_bn_bwd_reduce(const float* dy, const float* x, const float* y, const float* mean, const float* var,
-                                float eps, int32_t relu, int64_t V, int32_t C, void* ws, int64_t ws_bytes, float* sum_g,
-                                float* sum_gx, hipStream_t stream) {
+                                const float* gamma, const float* beta, float eps, int32_t relu, int64_t V, int32_t C,
+                                void* ws, int64_t ws_bytes, float* sum_g, float* sum_gx, hipStream_t stream) {
   int rc = check_vc("lt_bn_bwd_reduce", V, C);
   if (rc) return rc;
-  LT_REQUIRE(dy && x && mean && var && ws && sum_g && sum_gx && (!relu || y), LT_ERR_ARG, "lt_bn_bwd_reduce: null pointer");
+  LT_REQUIRE(relu >= 0 && relu <= 2, LT_ERR_ARG, "lt_bn_bwd_reduce: relu=%d not in {0,1,2}", relu);
+  LT_REQUIRE(dy && x && mean && var && ws && sum_g && sum_gx && (relu != 1 || y) && (relu != 2 || (gamma && beta)),
+             LT_ERR_ARG, "lt_bn_bwd_reduce: null pointer");
   LT_REQUIRE(ws_bytes >= lt_bn_workspace_bytes(V, C), LT_ERR_WORKSPACE, "lt_bn_bwd_reduce: workspace too small");
   const int nb = bn_blocks(V, C);
   const int cg = C / 4, rpi = BN_BLOCK / cg > 0 ? BN_BLOCK / cg : 1;
-  BwdOp op{dy, x, relu ? y : nullptr, mean, var, eps};
+  BwdOp op{dy, x, relu == 1 ? y : nullptr, mean, var, eps, relu == 2 ? gamma : nullptr, relu == 2 ? beta : nullptr};
   hipLaunchKernelGGL(k_col_partial<BwdOp>, dim3(nb), dim3(BN_BLOCK), (size_t)rpi * 2 * C * 4, stream, op, V, C,
                      (float*)ws);
   LT_LAUNCH_CHECK();
@@ -284,9 +302,10 @@ extern "C" int lt_bn_bwd_reduce(const float* dy, const float* x, const float* y,
 
 __global__ void k_bn_bwd_apply(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y,
                                const float* __restrict__ mean, const float* __restrict__ var,
-                               const float* __restrict__ gamma, float eps, const float* __restrict__ sum_g,
-                               const float* __restrict__ sum_gx, float* __restrict__ dx, float* __restrict__ dres,
-                               int64_t n4, int cg_n, float inv_v) {
+                               const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                               const float* __restrict__ sum_g, const float* __restrict__ sum_gx,
+                               float* __restrict__ dx, float* __restrict__ dres, int64_t n4, int cg_n, float inv_v) {
+  // beta != null: the ReLU mask is rebuilt from x (y is null then)
   for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n4; e += (int64_t)gridDim.x * blockDim.x) {
     const int cg = (int)(e % cg_n);
     float4 g = reinterpret_cast<const float4*>(dy)[e];
@@ -294,6 +313,17 @@ __global__ void k_bn_bwd_apply(const float* __restrict__ dy, const float* __rest
       const float4 yy = reinterpret_cast<const float4*>(y)[e];
       g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
       g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
+    }
+    if (beta) {
+      const float4 v = reinterpret_cast<const float4*>(x)[e];
+      const float4 m = reinterpret_cast<const float4*>(mean)[cg];
+      const float4 vr = reinterpret_cast<const float4*>(var)[cg];
+      const float4 gm = reinterpret_cast<const float4*>(gamma)[cg];
+      const float4 bt = reinterpret_cast<const float4*>(beta)[cg];
+      g.x = bn_affine(v.x, m.x, vr.x, gm.x, bt.x, eps) > 0.f ? g.x : 0.f;
+      g.y = bn_affine(v.y, m.y, vr.y, gm.y, bt.y, eps) > 0.f ? g.y : 0.f;
+      g.z = bn_affine(v.z, m.z, vr.z, gm.z, bt.z, eps) > 0.f ? g.z : 0.f;
+      g.w = bn_affine(v.w, m.w, vr.w, gm.w, bt.w, eps) > 0.f ? g.w : 0.f;
     }
     if (dres) reinterpret_cast<float4*>(dres)[e] = g;
     if (dx) {
@@ -315,15 +345,16 @@ __global__ void k_bn_bwd_apply(const float* __restrict__ dy, const float* __rest
 }
 
 extern "C" int lt_bn_bwd_apply(const float* dy, const float* x, const float* y, const float* mean, const float* var,
-                               const float* gamma, float eps, int32_t relu, const float* sum_g, const float* sum_gx,
-                               float* dx, float* dres, int64_t V, int32_t C, hipStream_t stream) {
+                               const float* gamma, const float* beta, float eps, int32_t relu, const float* sum_g,
+                               const float* sum_gx, float* dx, float* dres, int64_t V, int32_t C, hipStream_t stream) {
   int rc = check_vc("lt_bn_bwd_apply", V, C);
   if (rc) return rc;
-  LT_REQUIRE(dy && x && mean && var && gamma && sum_g && sum_gx && (!relu || y), LT_ERR_ARG,
+  LT_REQUIRE(relu >= 0 && relu <= 2, LT_ERR_ARG, "lt_bn_bwd_apply: relu=%d not in {0,1,2}", relu);
+  LT_REQUIRE(dy && x && mean && var && gamma && sum_g && sum_gx && (relu != 1 || y) && (relu != 2 || beta), LT_ERR_ARG,
              "lt_bn_bwd_apply: null pointer");
   const int64_t n4 = V * (C / 4);
-  hipLaunchKernelGGL(k_bn_bwd_apply, dim3(lt_grid(n4, 256)), dim3(256), 0, stream, dy, x, relu ? y : nullptr, mean, var,
-                     gamma, eps, sum_g, sum_gx, dx, dres, n4, C / 4, 1.0f / (float)V);
+  hipLaunchKernelGGL(k_bn_bwd_apply, dim3(lt_grid(n4, 256)), dim3(256), 0, stream, dy, x, relu == 1 ? y : nullptr, mean,
+                     var, gamma, relu == 2 ? beta : nullptr, eps, sum_g, sum_gx, dx, dres, n4, C / 4, 1.0f / (float)V);
   LT_LAUNCH_CHECK();
   return LT_OK;
 }

@@ -193,19 +193,20 @@ class _BatchNorm(Function):
         y = ops.bn_apply(x, mean, var, gamma, beta, eps, residual=residual, relu=relu)
         ctx.eps, ctx.relu = eps, relu
         ctx.has_res = residual is not None
-        ctx.save_for_backward(x, y if relu else None, mean, var, gamma)
+        # ReLU mask in the backward: from y when a residual was added, otherwise rebuilt from x (y is not read again)
+        ctx.save_for_backward(x, y if (relu and residual is not None) else None, mean, var, gamma, beta)
         if stats_out is not None:
             stats_out.append((mean, var))
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, mean, var, gamma = ctx.saved_tensors
+        x, y, mean, var, gamma, beta = ctx.saved_tensors
         dy = dy.contiguous()
         need_dx = ctx.needs_input_grad[0]
         need_dres = ctx.has_res and ctx.needs_input_grad[3]
         dx, dgamma, dbeta, dres = ops.bn_bwd(dy, x, y, mean, var, gamma, ctx.eps, ctx.relu, need_dx=need_dx,
-                                             need_dres=need_dres)
+                                             need_dres=need_dres, beta=beta)
         return dx, dgamma, dbeta, dres, None, None, None
 
 
@@ -229,12 +230,12 @@ class _ConvBN(Function):
         ctx.kmap, ctx.transposed, ctx.relu, ctx.eps, ctx.wcache = kmap, transposed, relu, eps, wcache
         ctx.cin, ctx.n_in = cin, feats.shape[0]
         ctx.has_res = residual is not None
-        ctx.save_for_backward(conv_out, y if relu else None, mean, var, gamma, weight)
+        ctx.save_for_backward(conv_out, y if (relu and residual is not None) else None, mean, var, gamma, weight, beta)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        conv_out, y, mean, var, gamma, weight = ctx.saved_tensors
+        conv_out, y, mean, var, gamma, weight, beta = ctx.saved_tensors
         kmap, transposed = ctx.kmap, ctx.transposed
         dy = dy.contiguous()
         packed_bwd = plan_bwd = None
@@ -249,7 +250,7 @@ class _ConvBN(Function):
                 packed_bwd, plan_bwd = _packed(weight, 1, ctx.wcache), kmap.plan()
         need_dres = ctx.has_res and ctx.needs_input_grad[4]
         din, dgamma, dbeta, dres = ops.conv_bn_bwd(dy, conv_out, y, mean, var, gamma.detach(), ctx.eps, ctx.relu, need_dres,
-                                                   packed_bwd, plan_bwd, kmap.K, ctx.n_in, ctx.cin)
+                                                   packed_bwd, plan_bwd, kmap.K, ctx.n_in, ctx.cin, beta=beta.detach())
         return din, None, dgamma, dbeta, dres, None, None, None, None, None
 
 

@@ -280,8 +280,20 @@ def bn_apply(x, mean, var, gamma, beta, eps: float, residual=None, relu: bool = 
     return y
 
 
-def bn_bwd(dy, x, y, mean, var, gamma, eps: float, relu: bool, need_dx=True, need_dres=False):
-    """-> (dx | None, dgamma, dbeta, dres | None)."""
+def _relu_mode(relu: bool, y, beta) -> int:
+    """0 = no ReLU; 1 = mask from the saved output y; 2 = no y saved (the forward added no residual): the kernels rebuild
+    the mask from x, gamma, beta with the forward's own expression"""
+    if not relu:
+        return 0
+    if y is not None:
+        return 1
+    if beta is None:
+        raise ValueError("ReLU backward needs the saved output y, or beta to rebuild the mask from x")
+    return 2
+
+
+def bn_bwd(dy, x, y, mean, var, gamma, eps: float, relu: bool, need_dx=True, need_dres=False, beta=None):
+    """-> (dx | None, dgamma, dbeta, dres | None).  y None with relu: mask rebuilt from x (needs beta; no residual)."""
     dy = _chk(dy, torch.float32, "bn_bwd dy")
     x = _chk(x, torch.float32, "bn_bwd x")
     V, C = x.shape
@@ -289,15 +301,17 @@ def bn_bwd(dy, x, y, mean, var, gamma, eps: float, relu: bool, need_dx=True, nee
     ws = _ws(lib.lt_bn_workspace_bytes(V, C), x.device)
     sum_g = torch.empty(C, dtype=torch.float32, device=x.device)
     sum_gx = torch.empty(C, dtype=torch.float32, device=x.device)
-    yp = _p(y) if relu else None
-    _lib.call("lt_bn_bwd_reduce", _p(dy), _p(x), yp, _p(mean), _p(var), float(eps), int(relu), V, C, _p(ws),
+    mode = _relu_mode(relu, y, beta)
+    yp = _p(y) if mode == 1 else None
+    gp = _p(_chk(gamma.detach(), torch.float32, "gamma"))
+    bp = _p(_chk(beta.detach(), torch.float32, "beta")) if beta is not None else None
+    _lib.call("lt_bn_bwd_reduce", _p(dy), _p(x), yp, _p(mean), _p(var), gp, bp, float(eps), mode, V, C, _p(ws),
               ws.numel(), _p(sum_g), _p(sum_gx), _stream())
     dx = torch.empty_like(x) if need_dx else None
     dres = torch.empty_like(x) if need_dres else None
     if need_dx or need_dres:
-        _lib.call("lt_bn_bwd_apply", _p(dy), _p(x), yp, _p(mean), _p(var),
-                  _p(_chk(gamma.detach(), torch.float32, "gamma")), float(eps), int(relu), _p(sum_g), _p(sum_gx),
-                  _p(dx), _p(dres), V, C, _stream())
+        _lib.call("lt_bn_bwd_apply", _p(dy), _p(x), yp, _p(mean), _p(var), gp, bp, float(eps), mode, _p(sum_g),
+                  _p(sum_gx), _p(dx), _p(dres), V, C, _stream())
     return dx, sum_gx, sum_g, dres
 
 
@@ -526,8 +540,9 @@ def conv_bn_fwd(feats, packed, plan, K: int, Vout: int, cout: int, gamma, beta, 
 
 
 def conv_bn_bwd(dy, conv_out, y, mean, var, gamma, eps: float, relu: bool, need_dres: bool, packed_bwd, plan_bwd,
-                K: int, Vin: int, cin: int):
-    """-> (din | None, dgamma, dbeta, dres | None); din is computed when packed_bwd is given."""
+                K: int, Vin: int, cin: int, beta=None):
+    """-> (din | None, dgamma, dbeta, dres | None); din is computed when packed_bwd is given.  y None with relu: the
+    ReLU mask is rebuilt from conv_out (needs beta; the forward added no residual)."""
     Vout, cout = conv_out.shape
     dev = conv_out.device
     lib = _lib.load()
@@ -538,8 +553,9 @@ def conv_bn_bwd(dy, conv_out, y, mean, var, gamma, eps: float, relu: bool, need_
     need_din = packed_bwd is not None
     dconv = torch.empty_like(conv_out) if need_din else None
     din = torch.empty((Vin, cin), dtype=torch.float32, device=dev) if need_din else None
-    yp = _p(y) if relu else None
-    _lib.call("lt_conv_bn_bwd", _p(dy), _p(conv_out), yp, _p(mean), _p(var), _p(gamma), float(eps), int(relu), Vout,
+    mode = _relu_mode(relu, y, beta)
+    yp = _p(y) if mode == 1 else None
+    _lib.call("lt_conv_bn_bwd", _p(dy), _p(conv_out), yp, _p(mean), _p(var), _p(gamma), _p(beta), float(eps), mode, Vout,
               cout, _p(ws), ws.numel(), _p(dgamma), _p(dbeta), _p(dres), _p(dconv), _p(packed_bwd), _p(plan_bwd),
               Vin, cin, K, _p(din), _stream())
     return din, dgamma, dbeta, dres

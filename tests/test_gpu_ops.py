@@ -181,6 +181,23 @@ def _sk_variants(cout):
             if (cout // 16) % ntw == 0]
 
 
+def _sj_variants(cin, cout):
+    """split-j variant codes 2000 + 100*SR + 10*NTW + W valid for these widths (W divides Cin/16)"""
+    return [2000 + 100 * sr + 10 * ntw + w for sr in (1, 2) for ntw in (2, 3, 4) for w in (2, 3, 4, 6, 8)
+            if (cout // 16) % ntw == 0 and (cin // 16) % w == 0]
+
+
+def _check_sj(ops, a, feats, pw, plan, K, vout, cin, cout):
+    """split-j kernels: within fp32 rounding of the single chain `a`, bit for bit from run to run, and bit for bit equal
+    to the flat split-k kernel of the same shape (same slab -> wave assignment and summation order when W | Cin/16)"""
+    for v in _sj_variants(cin, cout):
+        b = ops.spconv_plan(feats, pw, plan, K, vout, cout, variant=v)
+        assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max()), v
+        assert torch.equal(b, ops.spconv_plan(feats, pw, plan, K, vout, cout, variant=v)), v
+        if v % 10 in (2, 4, 8):
+            assert torch.equal(b, ops.spconv_plan(feats, pw, plan, K, vout, cout, variant=v - 1000)), v
+
+
 @pytest.mark.parametrize("cin,cout", [(16, 16), (32, 32), (32, 64), (96, 96), (128, 96), (192, 128), (384, 256), (48, 48),
                                       (64, 80)])
 @pytest.mark.parametrize("ks,stride", [(3, 1), (2, 2)])
@@ -207,6 +224,7 @@ def test_spconv_plan_is_bitwise_equal_to_table_kernel(scans_small, cin, cout, ks
         b = ops.spconv_plan(feats, pw, plan, K, resd.shape[1], cout, variant=v)
         assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max()), v
         assert torch.equal(b, ops.spconv_plan(feats, pw, plan, K, resd.shape[1], cout, variant=v)), v
+    _check_sj(ops, a, feats, pw, plan, K, resd.shape[1], cin, cout)
     rev = ops.kmap_reverse(resd, c.shape[0])
     gout = torch.randn(out_coords.shape[0], cout, generator=g).cuda()
     pwt = ops.pack_weights(w, 1)
@@ -218,6 +236,7 @@ def test_spconv_plan_is_bitwise_equal_to_table_kernel(scans_small, cin, cout, ks
     for v in [0] + _sk_variants(cin):
         b = ops.spconv_plan(gout, pwt, rplan, K, c.shape[0], cin, variant=v)
         assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max()), v
+    _check_sj(ops, a, gout, pwt, rplan, K, c.shape[0], cout, cin)
 
 
 def test_spconv_plan_empty_rows_and_ragged_tail():
@@ -238,7 +257,7 @@ def test_spconv_plan_empty_rows_and_ragged_tail():
         b = ops.spconv_plan(feats, pw, plan, K, V, C, variant=v)
         assert torch.equal(a, b), v
         assert float(b[5].abs().max()) == 0.0
-    for v in [0] + _sk_variants(C):
+    for v in [0] + _sk_variants(C) + _sj_variants(C, C):
         b = ops.spconv_plan(feats, pw, plan, K, V, C, variant=v)
         assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max()), v
         assert float(b[5].abs().max()) == 0.0
@@ -277,11 +296,19 @@ def test_batchnorm_fwd_bwd_matches_torch(V, C, relu, res):
         assert rel_err(dbeta.cpu(), beta.grad) < 1e-4
         if res:
             assert rel_err(dres.cpu(), r.grad) < 1e-6
+        if relu and not res:
+            # no residual: the backward can rebuild the ReLU mask from x instead of reading y (relu mode 2 of
+            # lt_bn_bwd_reduce / lt_bn_bwd_apply) -- bit for bit the result of the mask taken from the GPU's own y
+            a = ops.bn_bwd(dy.cuda(), xc, yg, mean, var, gamma.detach().cuda(), eps, True, need_dx=True)
+            b = ops.bn_bwd(dy.cuda(), xc, None, mean, var, gamma.detach().cuda(), eps, True, need_dx=True,
+                           beta=beta.detach().cuda())
+            for u, v in zip(a[:3], b[:3]):
+                assert torch.equal(u, v)
 
 
 @pytest.mark.parametrize("cin,cout", [(32, 32), (96, 48), (64, 256), (128, 80)])
 @pytest.mark.parametrize("ks,stride,transposed", [(3, 1, False), (2, 2, False), (2, 2, True)])
-@pytest.mark.parametrize("relu,res", [(False, False), (True, True)])
+@pytest.mark.parametrize("relu,res", [(False, False), (True, False), (True, True)])
 def test_conv_bn_composite_matches_unfused_ops(scans_small, cin, cout, ks, stride, transposed, relu, res):
     """lt_conv_bn_fwd / lt_conv_bn_bwd (BN statistics from the conv epilogue) against conv -> bn_stats -> bn_apply and
     their backward: the conv output bitwise, statistics / BN output / gradients to fp32 rounding.  Also with bench.py's

@@ -16,9 +16,17 @@ def main():
     for r in csv.DictReader(open(path)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Queue_Id", "0"), r["Kernel_Name"]))
     rows.sort()
-    t0, t1 = rows[0][0], max(r[1] for r in rows)
-    lo = t1 - int((t1 - t0) * tail)  # the last part of the run = timed steps (warm-up and setup come first)
-    rows = [r for r in rows if r[0] >= lo]
+    # one whole TTA step: from the start of the 4-channel stem conv of one teacher forward to the start of the next one
+    # (k_spconv_scalar runs twice per step: teacher, student)
+    stem = [r[0] for r in rows if "k_spconv_scalar" in r[3]]
+    nsteps = int(sys.argv[sys.argv.index("--steps") + 1]) if "--steps" in sys.argv else 2
+    if len(stem) >= 2 * (nsteps + 1):
+        lo, hi = stem[-2 * (nsteps + 1)], stem[-2]
+    else:
+        t0, t1 = rows[0][0], max(r[1] for r in rows)
+        lo, hi = t1 - int((t1 - t0) * tail), t1
+    rows = [r for r in rows if lo <= r[0] < hi]
+    print(f"{nsteps} step(s)")
     span = (max(r[1] for r in rows) - rows[0][0]) / 1e6
     print(f"window {span:.2f} ms, {len(rows)} dispatches")
     byq = collections.defaultdict(list)
@@ -47,7 +55,7 @@ def main():
             k = r[3].split("(")[0][:70]
             agg[k][0] += 1
             agg[k][1] += r[1] - r[0]
-        for k, (n, d) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:14]:
+        for k, (n, d) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
             print(f"    {d / 1e6:8.3f} ms {n:6d}  {k}")
 
 
