@@ -11,7 +11,7 @@ per step and GPU, 16 classes, SPVCNN cr=1.0, fp32); every rank owns its own sequ
 collective).  Inputs are resident in HBM before the timed region.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline      the dominant kernel family (sparse-conv fp32 MFMA kernel): algorithmic flops / HIP-event time of its
+  roofline      the dominant kernel family (sparse-conv fp32 MFMA kernel k_spconv_sj): algorithmic flops / HIP-event time of its
                 launches of a sample of the timed steps (the library's conv launch timer, lt_conv_timer_begin/end)
   cpu_baseline  the CPU oracle (oracle/step_ref.py, a port: the reference's torchsparse backend is not installable)
                 timed on this box's host cores on a bounded sample of the same workload
@@ -179,8 +179,8 @@ def main():
             achieved = flops_total / (ms_total * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                    "kernel": "k_spconv_rf<SR,NTW,W,split-k> (+k_spconv_scalar for the 4-channel stem): fp32 MFMA sparse conv, "
-                              "every launch of the sampled steps of the timed region",
+                    "kernel": "k_spconv_sj<SR,NTW,W> (split-j; +k_spconv_scalar for the 4-channel stem): fp32 MFMA sparse "
+                              "conv, every launch of the sampled steps of the timed region",
                     "launches": launches, "avg_launch_us": round(1e3 * ms_total / launches, 2),
                     "flops_per_launch": round(flops_total / launches),
                     "timed_steps": sampled,
