@@ -87,6 +87,17 @@ def pc2img_logit(pc_logits: torch.Tensor, pc2img_idx_ls: List[torch.Tensor]):
     return mask, pc_logits[mask]
 
 
+def cross_entropy(logits: torch.Tensor, target: torch.Tensor, weight=None, ignore_index: int = -100) -> torch.Tensor:
+    """F.cross_entropy(logits, target, weight, ignore_index=-100, reduction='mean') (latte.py:288-299) out of gather / sum
+    kernels: torch's nll_loss forward and backward reduce in ONE workgroup (92 us + 67 us per call at 209 k points)."""
+    logp = F.log_softmax(logits, 1)
+    valid = target != ignore_index
+    idx = torch.where(valid, target, torch.zeros_like(target))
+    picked = logp.gather(1, idx.unsqueeze(1)).squeeze(1)
+    w = valid.to(logp.dtype) if weight is None else weight[idx] * valid
+    return -(picked * w).sum() / w.sum()
+
+
 def allreduce_mean_grads(params: List[torch.Tensor], world: int, group=None) -> None:
     """The only collective of the path: ONE flat all-reduce (RCCL over xGMI on GPUs, gloo in the CPU tests) of the
     gradients of `params` (the norm parameters: 13 248 floats at cr=1), averaged over the ranks, written back as views
@@ -285,8 +296,8 @@ class LatteStep:
         hr32.update({"ac_pc_ety": pc3, "tr_pc_ety": pc2})
         l32 = self.cr(hr32)
         loss_3d.append(self.lam32 * l32)
-        pl2 = F.cross_entropy(preds_2d["seg_logit"], ps_label[fov_idx].long(), weight=self.class_weights)
-        pl3 = F.cross_entropy(preds_3d["seg_logit"], ps_label.long(), weight=self.class_weights)
+        pl2 = cross_entropy(preds_2d["seg_logit"], ps_label[fov_idx].long(), weight=self.class_weights)
+        pl3 = cross_entropy(preds_3d["seg_logit"], ps_label.long(), weight=self.class_weights)
         loss_2d.append(pl2)
         loss_3d.append(pl3)
         self._tick("cr_ce")

@@ -97,3 +97,22 @@ def test_synthetic_workloads_cover_baseline_configs():
     p2, _ = synth.make_scan(34816, 0, beams=32, full_360=True)
     p3, _ = synth.make_scan(34816, 0, beams=32, full_360=True)
     assert np.array_equal(p2, p3)   # deterministic
+
+
+def test_cross_entropy_matches_torch():
+    """tta_step.cross_entropy (gather/sum formulation) against F.cross_entropy: value and gradient, with ignored labels and
+    with class weights"""
+    import torch
+    import torch.nn.functional as F
+    from latte_amd.tta_step import cross_entropy
+    g = torch.Generator().manual_seed(5)
+    for weight in (None, torch.rand(7, generator=g) + 0.5):
+        x = torch.randn(300, 7, generator=g, requires_grad=True)
+        y = torch.randint(0, 7, (300,), generator=g)
+        y[::5] = -100
+        a = cross_entropy(x, y, weight)
+        ga, = torch.autograd.grad(a, x)
+        b = F.cross_entropy(x, y, weight=weight)
+        gb, = torch.autograd.grad(b, x)
+        assert abs(float(a) - float(b)) < 1e-6 * abs(float(b))
+        assert float((ga - gb).abs().max()) < 1e-7

@@ -52,10 +52,11 @@ def main():
               f"gaps>=50us: {sum(g for g in gaps if g >= 50_000) / 1e6:.2f} ms")
         agg = collections.defaultdict(lambda: [0, 0])
         for r in rs:
-            k = r[3].split("(")[0][:70]
+            k = r[3].replace("(anonymous namespace)::", "").replace("at::native::", "")
+            k = k.split("(")[0][:110]
             agg[k][0] += 1
             agg[k][1] += r[1] - r[0]
-        for k, (n, d) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
+        for k, (n, d) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:60]:
             print(f"    {d / 1e6:8.3f} ms {n:6d}  {k}")
 
 
