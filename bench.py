@@ -94,17 +94,27 @@ def main():
     from latte_amd.tta_step import LatteStep, shard_scan_offset
     from latte_amd.workload import build_batch, hr_cfg_of
 
+    if os.environ.get("LATTE_BENCH_TRACE"):  # where a stuck multi-rank run stands: Python stacks of every rank after 60 s
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["LATTE_BENCH_TRACE"]), exit=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     _lib.load()
+    # LATTE_BENCH_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks (ranks share GPUs)
+    backend = os.environ.get("LATTE_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     pg = None
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
         pg = dist.group.WORLD
 
     w = synth.workload(args.workload)
@@ -145,7 +155,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     trace = ops.conv_timer_end() if timed_kernels else None
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())

@@ -244,8 +244,12 @@ extern "C" int lt_bn_finalize_sums(void* stats_ws, int64_t V, int32_t C, float* 
 __global__ void k_bn_apply(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ var,
                            const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                            const float* __restrict__ res, int relu, float* __restrict__ y, int64_t n4, int cg_n) {
-  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n4; e += (int64_t)gridDim.x * blockDim.x) {
-    const int cg = (int)(e % cg_n);
+  // column group of element e without a 64-bit modulo per element: one modulo per thread, then a wrapped increment
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int cstep = (int)(stride % cg_n);
+  int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int cg = (int)(e % cg_n);
+  for (; e < n4; e += stride, cg = cg + cstep >= cg_n ? cg + cstep - cg_n : cg + cstep) {
     const float4 v = reinterpret_cast<const float4*>(x)[e];
     const float4 m = reinterpret_cast<const float4*>(mean)[cg];
     const float4 vr = reinterpret_cast<const float4*>(var)[cg];
@@ -306,8 +310,11 @@ __global__ void k_bn_bwd_apply(const float* __restrict__ dy, const float* __rest
                                const float* __restrict__ sum_g, const float* __restrict__ sum_gx,
                                float* __restrict__ dx, float* __restrict__ dres, int64_t n4, int cg_n, float inv_v) {
   // beta != null: the ReLU mask is rebuilt from x (y is null then)
-  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n4; e += (int64_t)gridDim.x * blockDim.x) {
-    const int cg = (int)(e % cg_n);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int cstep = (int)(stride % cg_n);
+  int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int cg = (int)(e % cg_n);
+  for (; e < n4; e += stride, cg = cg + cstep >= cg_n ? cg + cstep - cg_n : cg + cstep) {
     float4 g = reinterpret_cast<const float4*>(dy)[e];
     if (y) {
       const float4 yy = reinterpret_cast<const float4*>(y)[e];
