@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--all-kernel-events", action="store_true", help="time the conv launches of every timed step")
     ap.add_argument("--no-side-stream", action="store_true", help="run the input-only, sync-heavy work (index structures, "
                     "HR geometry) on the main stream too")
+    ap.add_argument("--no-prefetch", action="store_true", help="build the index structures of a batch inside its own step "
+                    "instead of one step ahead")
     ap.add_argument("--dump-conv", default=None, help="write the per-launch conv table of one step (JSON) here")
     ap.add_argument("--fwd-only", action="store_true", help="time teacher forward only (BASELINE config 5 style)")
     return ap.parse_args()
@@ -128,7 +130,9 @@ def main():
         if args.fwd_only:
             with torch.no_grad():
                 return step.ema_model(batch)
-        return step.step(batch)
+        # the synthetic workload feeds the same scans every step: `next_batch=batch` makes the step issue the NEXT
+        # iteration's input-only structures (rebuilt from the coordinates, not reused) while its own backward runs
+        return step.step(batch, next_batch=None if args.no_prefetch else batch)
 
     for _ in range(args.warmup):
         one_step()

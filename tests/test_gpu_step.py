@@ -73,3 +73,31 @@ def test_step_updates_norm_parameters_only_and_ema_follows():
     assert cache is not None and "x0" in cache
     step.step(batch)
     assert batch["lidar"]._lt_cache is not cache
+
+
+def test_prefetch_one_iteration_ahead_changes_no_result():
+    """step(batch, next_batch=...) issues the next iteration's input-only structures (index structures, in-FOV tables, HR
+    geometry) on the side stream at the end of the current one: same losses and same parameters as building them inside
+    each iteration (to the run-to-run noise of the step's torch index_add atomics, ~1e-7), and the structures are
+    rebuilt, not reused."""
+    _, step_a, batch_a = _setup()
+    _, step_b, batch_b = _setup()
+    la, lb = [], []
+    for _ in range(3):
+        la.append({k: float(v) for k, v in step_a.step(batch_a).items()})
+    caches = []
+    for _ in range(3):
+        lb.append({k: float(v) for k, v in step_b.step(batch_b, next_batch=batch_b).items()})
+        assert step_b._pre is not None and step_b._pre[0] is batch_b      # the next iteration's structures are on their way
+        caches.append(batch_b["lidar"]._lt_cache)
+    assert caches[0] is not caches[1] and caches[1] is not caches[2]      # rebuilt every iteration
+    for a, b in zip(la, lb):
+        for k in a:
+            assert abs(a[k] - b[k]) <= 1e-5 * abs(a[k]), (k, la, lb)
+    torch.cuda.synchronize()
+    for (ka, va), (kb, vb) in zip(step_a.model.state_dict().items(), step_b.model.state_dict().items()):
+        assert ka == kb and torch.allclose(va, vb, rtol=1e-4, atol=1e-6), ka
+    # a different batch than the one announced: the prefetched structures are dropped, the step builds its own
+    _, _, other = _setup()
+    l_other = step_b.step(other)
+    assert step_b._pre is None and all(np.isfinite(float(v)) for v in l_other.values())
