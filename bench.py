@@ -154,6 +154,7 @@ def main():
             ops.conv_timer_arm(False)
         else:
             one_step()
+    dt_host = time.perf_counter() - t0  # the host has issued every step (the GPU may still be working)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -173,6 +174,7 @@ def main():
         pairs = [int(m.item()) for m in ops.CONV_PAIRS]
         ops.CONV_PAIRS = None
 
+    step.close()
     if rank == 0:
         roof = None
         if timed_kernels:
@@ -216,6 +218,7 @@ def main():
             "config": {"workload": args.workload, "scans_per_gpu": w["B"], "points_per_scan": w["n"], "classes": w["C"],
                        "st_window": w["W"], "st_voxel_m": w["vs"], "max_range_m": w["R"], "spvcnn_cr": args.cr,
                        "voxels_per_gpu": batch["n_voxels"], "parallelism": f"dp{world} (sequences sharded)"},
+            "host_issue_ms_per_step": round(1e3 * dt_host / args.steps, 3),
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

@@ -230,24 +230,58 @@ class LatteStep:
     def prefetch(self, batch: Dict) -> None:
         """Everything of one iteration that depends on the INPUTS of `batch` only -- the index structures of the backbone
         (voxel sets, kernel maps, conv plans, point<->voxel maps and CSRs), the in-FOV tables, the geometry of both HR
-        calls: ~350 small kernels and ~25 host syncs -- issued on the side stream NOW, i.e. while the GPU still works on
-        the previous iteration's backward.  step(batch) then finds them ready; it builds them itself otherwise.  Nothing
-        is reused: the structures are rebuilt from the coordinates for every iteration, one iteration ahead.  (Measured:
-        built inside the iteration they cost 4 ms of 26.6 although they run on their own stream -- the host blocks in
-        their syncs and the main stream runs dry.)"""
+        calls: ~350 small kernels and ~25 host syncs -- built on the side stream by a HELPER THREAD, starting now.
+        step(batch) later joins the thread and finds them ready; it builds them itself otherwise.  Nothing is reused: the
+        structures are rebuilt from the coordinates for every iteration, one iteration ahead.
+
+        Why a thread: the step is host-bound otherwise (bench.py's host_issue_ms_per_step = ms_per_step).  The
+        input-only work costs the host 11 of its 27 ms per step, nearly all of it blocked in the syncs that return
+        data-dependent sizes (each one drains the side stream); ctypes and torch release the GIL while they wait, so a
+        second thread turns that waiting into issue time for the main stream.  The helper touches no state of the step
+        in flight: it builds into a private SparseTensor view of the batch's lidar tensor and hands the result over at
+        the join."""
         side = self._side_stream()
         if side is None:
             return
-        batch["lidar"]._lt_cache = None
-        with torch.cuda.stream(side):
-            tab = self._batch_tables(batch)
-            self.model.net_3d.prepare(batch["lidar"])
-            a2, h2, a3, h3 = self._hr_inputs(batch, tab)
-            geo23 = self.hr.geometry(a2, "2D", h3, "3D")
-            geo32 = self.hr.geometry(a3, "3D", h2, "2D")
-        self._pre = (batch, tab, geo23, geo32)
+        import threading
+        from .tensor import SparseTensor
+        dev = batch["lidar"].C.device
+        box: Dict = {}
 
-    def forward_backward(self, batch: Dict):
+        def body():
+            try:
+                with torch.cuda.device(dev), torch.no_grad(), torch.cuda.stream(side):
+                    tab = self._batch_tables(batch)
+                    x = batch["lidar"]
+                    view = SparseTensor(x.F, x.C, x.s)   # same tensors, own cache slot
+                    self.model.net_3d.prepare(view)
+                    a2, h2, a3, h3 = self._hr_inputs(batch, tab)
+                    box["geo23"] = self.hr.geometry(a2, "2D", h3, "3D")
+                    box["geo32"] = self.hr.geometry(a3, "3D", h2, "2D")
+                    box["tab"], box["cache"] = tab, view._lt_cache
+            except BaseException as e:  # re-raised by the step that joins
+                box["error"] = e
+
+        th = threading.Thread(target=body, name="latte-prefetch", daemon=True)
+        th.start()
+        self._pre = (batch, th, box)
+
+    def _take_prefetched(self, batch: Dict):
+        """-> (tables, geo23, geo32) built ahead for `batch` by prefetch() (joins the helper thread, installs the index
+        structures on the batch), or None"""
+        pre, self._pre = self._pre, None
+        if pre is None:
+            return None
+        b, th, box = pre
+        th.join()
+        if "error" in box:
+            raise box["error"]
+        if b is not batch or self._side_stream() is None:
+            return None
+        batch["lidar"]._lt_cache = box["cache"]
+        return box["tab"], box["geo23"], box["geo32"]
+
+    def forward_backward(self, batch: Dict, pre=None):
         """-> dict of losses.  batch: see latte_amd.workload.build_batch.
 
         Stream plan (side stream on, the default): everything that depends on the INPUTS only and needs host syncs --
@@ -262,13 +296,10 @@ class LatteStep:
         preds_2d = {"seg_logit": batch["logit_2d_student"]}
         main = torch.cuda.current_stream()
         side = self._side_stream()
-        pre, self._pre = self._pre, None
-        if pre is not None and (pre[0] is not batch or side is None):
-            pre = None
         geo23 = geo32 = None
         if pre is not None:
             # built one iteration ahead by prefetch()
-            _, tab, geo23, geo32 = pre
+            tab, geo23, geo32 = pre
             main.wait_stream(side)
             _record_stream_tree(batch["lidar"]._lt_cache, main)
             _record_stream_tree(tab, main)
@@ -354,21 +385,26 @@ class LatteStep:
         allreduce_mean_grads(self.params, self.world, self.pg)
 
     def step(self, batch: Dict, next_batch: Dict | None = None):
-        """One TTA iteration on `batch`.  next_batch (optional): the batch of the NEXT iteration -- its input-only
-        structures are issued on the side stream at the end of this call (prefetch), so that they are built while the
-        GPU still executes this iteration's backward."""
+        """One TTA iteration on `batch`.  next_batch (optional): the batch of the NEXT iteration -- a helper thread starts
+        building its input-only structures on the side stream right away (prefetch), beside this iteration."""
         self._tick("step_begin")
         # one TTA iteration = one new batch: index structures are built once per iteration (ahead of it by prefetch(), or
         # by the teacher forward) and shared with the student forward, never carried over from an earlier iteration
-        if not _KEEP_CACHE and not (self._pre is not None and self._pre[0] is batch):
-            self._pre = None
+        pre = self._take_prefetched(batch)
+        if pre is None and not _KEEP_CACHE:
             batch["lidar"]._lt_cache = None
+        if next_batch is not None:
+            self.prefetch(next_batch)
         self.optimizer.zero_grad(set_to_none=True)
-        losses = self.forward_backward(batch)
+        losses = self.forward_backward(batch, pre)
         self.allreduce_grads()
         self.optimizer.step()
         update_ema_norm(self.ema_model, self.model, 0.99)
         self._tick("optim_ema")
-        if next_batch is not None:
-            self.prefetch(next_batch)
         return losses
+
+    def close(self) -> None:
+        """join a helper thread that is still running (end of the adaptation loop)"""
+        pre, self._pre = self._pre, None
+        if pre is not None:
+            pre[1].join()

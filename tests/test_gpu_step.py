@@ -101,3 +101,4 @@ def test_prefetch_one_iteration_ahead_changes_no_result():
     _, _, other = _setup()
     l_other = step_b.step(other)
     assert step_b._pre is None and all(np.isfinite(float(v)) for v in l_other.values())
+    step_b.close()
