@@ -61,9 +61,10 @@ def _norm_params(model: nn.Module) -> List[torch.Tensor]:
 
 
 @torch.no_grad()
-def update_ema_norm(ema_model: nn.Module, model: nn.Module, alpha: float = 0.99) -> nn.Module:
-    """ema = alpha*ema + (1-alpha)*student on the norm parameters (ema_util.update_ema_norm), as two multi-tensor ops."""
-    e, s = _norm_params(ema_model), _norm_params(model)
+def update_ema_norm(ema_model: nn.Module, model: nn.Module, alpha: float = 0.99, params=None) -> nn.Module:
+    """ema = alpha*ema + (1-alpha)*student on the norm parameters (ema_util.update_ema_norm), as two multi-tensor ops.
+    params: (ema list, student list) collected once by the caller (walking both module trees costs 1.2 ms per step)."""
+    e, s = params if params is not None else (_norm_params(ema_model), _norm_params(model))
     torch._foreach_mul_(e, alpha)
     torch._foreach_add_(e, s, alpha=1.0 - alpha)
     return ema_model
@@ -161,6 +162,7 @@ class LatteStep:
         self.cr = CR_Block(reduction="mean", conf_mask=True, ety_weight=True)
         self.params = [p for p in self.model.parameters() if p.requires_grad]
         self.optimizer = torch.optim.Adam(self.params, lr=lr)
+        self._ema_pairs = (_norm_params(self.ema_model), _norm_params(self.model))
         self.conf_perc = hr_cfg.get("conf_perc") if conf_perc is None else conf_perc
         self.lam23, self.lam32, self.lam_ps = lambda_hr_23, lambda_hr_32, lambda_ety_ps
         self.class_weights = class_weights
@@ -399,7 +401,7 @@ class LatteStep:
         losses = self.forward_backward(batch, pre)
         self.allreduce_grads()
         self.optimizer.step()
-        update_ema_norm(self.ema_model, self.model, 0.99)
+        update_ema_norm(self.ema_model, self.model, 0.99, self._ema_pairs)
         self._tick("optim_ema")
         return losses
 
