@@ -192,7 +192,8 @@ class LatteStep:
         import time
         torch.cuda.synchronize()
         now = time.perf_counter()
-        self.timers[name] = self.timers.get(name, 0.0) + (now - self._t_last)
+        if getattr(self, "_t_last", None) is not None:
+            self.timers[name] = self.timers.get(name, 0.0) + (now - self._t_last)
         self._t_last = now
 
     def _batch_tables(self, batch: Dict) -> Dict:
