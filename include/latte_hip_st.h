@@ -73,4 +73,15 @@ int lt_class_quantile_mask(const float* ety, const int32_t* label, int64_t n, in
 int lt_class_median_mask(const float* vals, const int32_t* label, int64_t n, int32_t num_classes, float cap, void* ws,
                          int64_t ws_bytes, uint8_t* keep, lt_stream_t stream);
 
+/* Entropy-weighted pseudo-label fusion of the two teachers (latte/tta/tools/latte.py:207-236; losses.py:10-19) as two
+ * kernels: logits_2d [Nf,C] of the in-FOV points, logits_3d [N,C] of all points, fov_idx [Nf] (unique rows of N),
+ * st_ety_* the ST-voxel entropies of HR_Block (0 = no ST voxel), thr_* device scalars = the conf_perc quantile of st_ety_*
+ * (NULL: no quantile filter).  Out: probs_3d [N,C] = softmax(logits_3d), pc_2d [Nf] / pc_3d [N] = point entropies with the
+ * ST entropy substituted where it is valid, ps_conf [N] / ps_label [N] = max / argmax of the fused probabilities (2-D and
+ * 3-D blended by exp(-entropy) weights inside the FOV, 3-D alone outside).  C <= 64. */
+int lt_pseudo_label_fuse(const float* logits_2d, const float* logits_3d, const int64_t* fov_idx, const float* st_ety_2d,
+                         const float* st_ety_3d, const float* thr_2d, const float* thr_3d, int64_t N, int64_t Nf, int32_t C,
+                         float* probs_3d, float* pc_2d, float* pc_3d, float* ps_conf, int32_t* ps_label,
+                         lt_stream_t stream);
+
 #endif

@@ -476,3 +476,94 @@ static int class_mask_impl(const float* ety, const int32_t* label, int64_t n, in
   LT_LAUNCH_CHECK();
   return LT_OK;
 }
+
+
+// ---------------------------------------------------------------- pseudo-label fusion (latte/tta/tools/latte.py:207-236)
+// Teacher logits of both modalities -> entropy-weighted pseudo labels, two kernels instead of ~25 elementwise launches:
+//   pc = per-point entropy of softmax(logits) (losses.py:10-19), replaced by the ST-voxel entropy st where st != 0 and
+//        st <= thr (thr = the global conf_perc quantile, a device scalar; NULL: no quantile filter)      latte.py:207-222
+//   all points: ps_prob = softmax(logits_3d);  in-FOV points: ps_prob = w2*softmax(logits_2d) + w3*softmax(logits_3d)
+//        with w2 = rv2/(rv2+rv3), w3 = rv3/(rv2+rv3), rv = exp(-pc)                                      latte.py:224-233
+//   ps_conf, ps_label = ps_prob.max(1)                                                                   latte.py:235
+// Pass 1 (k_pl_points3d) runs over all N points, pass 2 (k_pl_fov) over the Nf in-FOV points and overwrites their rows.
+__device__ __forceinline__ float pl_softmax_entropy(const float* row, int C, float* v) {
+#pragma clang fp contract(off)
+  const float log2c = (float)log2((double)C);
+  float mx = -INFINITY;
+  for (int c = 0; c < C; ++c) { v[c] = row[c]; mx = fmaxf(mx, v[c]); }
+  float sum = 0.f;
+  for (int c = 0; c < C; ++c) { v[c] = expf(v[c] - mx); sum += v[c]; }
+  float e = 0.f;
+  for (int c = 0; c < C; ++c) {
+    v[c] = v[c] / sum;
+    e += (-(v[c] * log2f(v[c] + 1e-30f))) / log2c;
+  }
+  return e;
+}
+
+__global__ void k_pl_points3d(const float* __restrict__ logits3, const float* __restrict__ st3, const float* __restrict__ thr3,
+                              int64_t N, int C, float* __restrict__ probs3, float* __restrict__ pc3,
+                              float* __restrict__ conf, int* __restrict__ label) {
+  const float t = thr3 ? *thr3 : INFINITY;
+  for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < N; p += (int64_t)gridDim.x * blockDim.x) {
+    float v[64];
+    float e = pl_softmax_entropy(logits3 + p * C, C, v);
+    const float s = st3[p];
+    if (s != 0.f && s <= t) e = s;
+    pc3[p] = e;
+    float best = v[0];
+    int arg = 0;
+    for (int c = 0; c < C; ++c) {
+      probs3[p * C + c] = v[c];
+      if (v[c] > best) { best = v[c]; arg = c; }
+    }
+    conf[p] = best;
+    label[p] = arg;
+  }
+}
+
+__global__ void k_pl_fov(const float* __restrict__ logits2, const float* __restrict__ st2, const float* __restrict__ thr2,
+                         const int64_t* __restrict__ fov_idx, const float* __restrict__ probs3,
+                         const float* __restrict__ pc3, int64_t Nf, int C, float* __restrict__ pc2,
+                         float* __restrict__ conf, int* __restrict__ label) {
+#pragma clang fp contract(off)
+  const float t = thr2 ? *thr2 : INFINITY;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < Nf; i += (int64_t)gridDim.x * blockDim.x) {
+    float v[64];
+    float e = pl_softmax_entropy(logits2 + i * C, C, v);
+    const float s = st2[i];
+    if (s != 0.f && s <= t) e = s;
+    pc2[i] = e;
+    const int64_t p = fov_idx[i];
+    const float rv2 = expf(-e), rv3 = expf(-pc3[p]);
+    const float w2 = rv2 / (rv2 + rv3), w3 = rv3 / (rv2 + rv3);
+    float best = -INFINITY;
+    int arg = 0;
+    for (int c = 0; c < C; ++c) {
+      const float m = w2 * v[c] + w3 * probs3[p * C + c];
+      if (m > best) { best = m; arg = c; }
+    }
+    conf[p] = best;
+    label[p] = arg;
+  }
+}
+
+extern "C" int lt_pseudo_label_fuse(const float* logits_2d, const float* logits_3d, const int64_t* fov_idx,
+                                    const float* st_ety_2d, const float* st_ety_3d, const float* thr_2d,
+                                    const float* thr_3d, int64_t N, int64_t Nf, int32_t C, float* probs_3d, float* pc_2d,
+                                    float* pc_3d, float* ps_conf, int32_t* ps_label, hipStream_t stream) {
+  LT_REQUIRE(N >= 0 && Nf >= 0 && C >= 1 && C <= 64, LT_ERR_ARG, "lt_pseudo_label_fuse: bad sizes (C=%d must be in [1,64])", C);
+  if (N == 0) return LT_OK;
+  LT_REQUIRE(logits_3d && st_ety_3d && probs_3d && pc_3d && ps_conf && ps_label, LT_ERR_ARG,
+             "lt_pseudo_label_fuse: null pointer");
+  hipLaunchKernelGGL(k_pl_points3d, dim3(lt_grid(N, 128)), dim3(128), 0, stream, logits_3d, st_ety_3d, thr_3d, N, C,
+                     probs_3d, pc_3d, ps_conf, ps_label);
+  LT_LAUNCH_CHECK();
+  if (Nf > 0) {
+    LT_REQUIRE(logits_2d && fov_idx && st_ety_2d && pc_2d, LT_ERR_ARG, "lt_pseudo_label_fuse: null pointer");
+    hipLaunchKernelGGL(k_pl_fov, dim3(lt_grid(Nf, 128)), dim3(128), 0, stream, logits_2d, st_ety_2d, thr_2d, fov_idx,
+                       probs_3d, pc_3d, Nf, C, pc_2d, ps_conf, ps_label);
+    LT_LAUNCH_CHECK();
+  }
+  return LT_OK;
+}

@@ -523,6 +523,29 @@ def class_median_mask(vals, label, num_classes: int, cap: float):
     return keep.bool()
 
 
+def pseudo_label_fuse(logits_2d, logits_3d, fov_idx, st_ety_2d, st_ety_3d, thr_2d=None, thr_3d=None):
+    """-> (pc_2d [Nf], pc_3d [N], ps_conf [N], ps_label int32 [N]); see lt_pseudo_label_fuse.  thr_*: 0-d device tensors."""
+    l2 = _chk(logits_2d, torch.float32, "pl logits_2d")
+    l3 = _chk(logits_3d, torch.float32, "pl logits_3d")
+    fi = _chk(fov_idx, torch.int64, "pl fov_idx")
+    s2 = _chk(st_ety_2d, torch.float32, "pl st_ety_2d")
+    s3 = _chk(st_ety_3d, torch.float32, "pl st_ety_3d")
+    N, C = l3.shape
+    Nf = l2.shape[0]
+    assert fi.numel() == Nf and s2.numel() == Nf and s3.numel() == N and l2.shape[1] == C
+    dev = l3.device
+    t2 = None if thr_2d is None else _chk(thr_2d.reshape(1), torch.float32, "pl thr_2d")
+    t3 = None if thr_3d is None else _chk(thr_3d.reshape(1), torch.float32, "pl thr_3d")
+    probs3 = torch.empty((N, C), dtype=torch.float32, device=dev)
+    pc2 = torch.empty(Nf, dtype=torch.float32, device=dev)
+    pc3 = torch.empty(N, dtype=torch.float32, device=dev)
+    conf = torch.empty(N, dtype=torch.float32, device=dev)
+    label = torch.empty(N, dtype=torch.int32, device=dev)
+    _lib.call("lt_pseudo_label_fuse", _p(l2), _p(l3), _p(fi), _p(s2), _p(s3), _p(t2), _p(t3), N, Nf, C, _p(probs3),
+              _p(pc2), _p(pc3), _p(conf), _p(label), _stream())
+    return pc2, pc3, conf, label
+
+
 # ------------------------------------------------------------------ conv -> BN [+ residual] [+ ReLU] composites
 def conv_bn_fwd(feats, packed, plan, K: int, Vout: int, cout: int, gamma, beta, eps: float, residual, relu: bool):
     """-> (conv_out, y, mean, var).  One host call (lt_conv_bn_fwd): conv with statistics epilogue, finalize, BN apply."""

@@ -18,7 +18,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .hr_module import CR_Block, HR_Block, prob_2_entropy
+from . import ops
+from .hr_module import CR_Block, HR_Block
 from .spvcnn import inverse_to_all
 
 __all__ = ["configure_model_norm", "create_ema_model", "update_ema_norm", "refine_pseudo_labels", "pc2img_logit",
@@ -76,7 +77,6 @@ def refine_pseudo_labels(probs: torch.Tensor, pseudo_label: torch.Tensor, ignore
     One sort + one threshold kernel + one mask kernel (lt_class_median_mask) instead of a per-class Python loop."""
     if num_classes is None:
         num_classes = int(pseudo_label.max().item()) + 1
-    from . import ops
     keep = ops.class_median_mask(probs.float().contiguous(), pseudo_label.to(torch.int32).contiguous(), num_classes, 0.9)
     return torch.where(keep, pseudo_label, torch.full_like(pseudo_label, ignore_label))
 
@@ -323,7 +323,6 @@ class LatteStep:
         with torch.no_grad():
             ema3d = self.ema_model(batch)
             ema3d["seg_logit"] = ema3d["seg_logit"][tab["inv_all"]]     # inverse_to_all
-            ema_logit_3d = ema3d["seg_logit"][fov_idx]                  # pc2img_logit
         self._tick("teacher_fwd")
         late_geo = side is not None and geo23 is None
         if late_geo:
@@ -346,25 +345,14 @@ class LatteStep:
 
         # ---- pseudo labels (latte.py:207-238); [pc2img_mask] indexing of the reference = gathers/scatters by fov_idx
         with torch.no_grad():
-            probs_2d = F.softmax(ema_logit_2d, 1)
-            all_probs_3d = F.softmax(ema3d["seg_logit"], 1)
-            probs_3d = F.softmax(ema_logit_3d, 1)
             st3, st2 = hr23["hs_pc_ety"], hr32["hs_pc_ety"]
-            v3, v2 = st3 != 0, st2 != 0
+            thr2 = thr3 = None
             if self.conf_perc is not None and self.conf_perc >= 0:
-                v3 = torch.logical_and(st3 <= torch.quantile(st3, self.conf_perc), v3)
-                v2 = torch.logical_and(st2 <= torch.quantile(st2, self.conf_perc), v2)
-            pc2 = prob_2_entropy(probs_2d).sum(1)
-            pc3 = prob_2_entropy(all_probs_3d).sum(1)
-            pc2 = torch.where(v2, st2, pc2)
-            pc3 = torch.where(v3, st3, pc3)
-            rv2, rv3 = torch.exp(-pc2), torch.exp(-pc3)
-            rv3m = rv3[fov_idx]
-            w2 = rv2 / (rv2 + rv3m)
-            w3 = rv3m / (rv2 + rv3m)
-            ps_prob = all_probs_3d
-            ps_prob.index_copy_(0, fov_idx, w2.unsqueeze(1) * probs_2d + w3.unsqueeze(1) * probs_3d)
-            ps_conf, ps_label = ps_prob.max(1)
+                thr3 = torch.quantile(st3, self.conf_perc)
+                thr2 = torch.quantile(st2, self.conf_perc)
+            # softmax x2, point entropies, ST-entropy substitution, exp(-entropy) blend inside the FOV, max: 2 kernels
+            pc2, pc3, ps_conf, ps_label = ops.pseudo_label_fuse(ema_logit_2d, ema3d["seg_logit"], fov_idx, st2, st3,
+                                                                thr2, thr3)
             ps_label = refine_pseudo_labels(ps_conf, ps_label, num_classes=self.num_classes)
 
         self._tick("pseudo_labels")

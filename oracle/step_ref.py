@@ -42,6 +42,29 @@ def inverse_to_all(logit: torch.Tensor, inverse_maps, sizes) -> torch.Tensor:
     return torch.cat(out, 0)
 
 
+def pseudo_label_fuse_ref(logit_2d_teacher: torch.Tensor, logit_3d_teacher: torch.Tensor, mask: torch.Tensor,
+                          st2: torch.Tensor, st3: torch.Tensor, cp):
+    """latte/tta/tools/latte.py:207-233: point entropies (ST-voxel entropy substituted where valid) and the fused
+    pseudo-label probabilities.  mask: bool [N] (in-FOV points); -> (pc2 [Nf], pc3 [N], ps_prob [N, C])."""
+    probs_2d = F.softmax(logit_2d_teacher, 1)
+    all_probs_3d = F.softmax(logit_3d_teacher, 1)
+    probs_3d = F.softmax(logit_3d_teacher[mask], 1)
+    v3, v2 = st3 != 0, st2 != 0
+    if cp is not None and cp >= 0:
+        v3 = torch.logical_and(st3 <= torch.quantile(st3, cp), v3)
+        v2 = torch.logical_and(st2 <= torch.quantile(st2, cp), v2)
+    pc2 = hr_ref.prob_2_entropy(probs_2d).sum(1)
+    pc3 = hr_ref.prob_2_entropy(all_probs_3d).sum(1)
+    pc2[v2] = st2[v2]
+    pc3[v3] = st3[v3]
+    rv2, rv3 = torch.exp(-pc2), torch.exp(-pc3)
+    w2 = rv2 / (rv2 + rv3[mask])
+    w3 = rv3[mask] / (rv2 + rv3[mask])
+    ps_prob = all_probs_3d
+    ps_prob[mask, :] = w2.unsqueeze(1) * probs_2d + w3.unsqueeze(1) * probs_3d
+    return pc2, pc3, ps_prob
+
+
 def tta_step_ref(student_sd: Dict, teacher_sd: Dict, coords: np.ndarray, feats: torch.Tensor, inverse_maps, sizes,
                  ori_points: List[torch.Tensor], fov_masks: List[torch.Tensor], poses, scene_names, scan_ids,
                  logit_2d_student: torch.Tensor, logit_2d_teacher: torch.Tensor, hr_cfg: Dict,
@@ -56,7 +79,6 @@ def tta_step_ref(student_sd: Dict, teacher_sd: Dict, coords: np.ndarray, feats: 
     with torch.no_grad():
         ema3d = inverse_to_all(teacher(coords, feats)["seg_logit"], inverse_maps, sizes)
         mask = torch.cat(list(fov_masks), 0)
-        ema_logit_3d = ema3d[mask]
     s3d = inverse_to_all(student(coords, feats)["seg_logit"], inverse_maps, sizes)
     ori_2d = [p[m] for p, m in zip(ori_points, fov_masks)]
     a2 = dict(seg_logit=l2s, ori_points=ori_2d, **extra)
@@ -68,24 +90,8 @@ def tta_step_ref(student_sd: Dict, teacher_sd: Dict, coords: np.ndarray, feats: 
     hr23 = hr_ref.hr_forward(a2, "2D", h3, "3D", **kw)
     hr32 = hr_ref.hr_forward(a3, "3D", h2, "2D", **kw)
     with torch.no_grad():
-        probs_2d = F.softmax(logit_2d_teacher, 1)
-        all_probs_3d = F.softmax(ema3d, 1)
-        probs_3d = F.softmax(ema_logit_3d, 1)
-        st3, st2 = hr23["hs_pc_ety"], hr32["hs_pc_ety"]
-        v3, v2 = st3 != 0, st2 != 0
-        cp = hr_cfg["conf_perc"]
-        if cp is not None and cp >= 0:
-            v3 = torch.logical_and(st3 <= torch.quantile(st3, cp), v3)
-            v2 = torch.logical_and(st2 <= torch.quantile(st2, cp), v2)
-        pc2 = hr_ref.prob_2_entropy(probs_2d).sum(1)
-        pc3 = hr_ref.prob_2_entropy(all_probs_3d).sum(1)
-        pc2[v2] = st2[v2]
-        pc3[v3] = st3[v3]
-        rv2, rv3 = torch.exp(-pc2), torch.exp(-pc3)
-        w2 = rv2 / (rv2 + rv3[mask])
-        w3 = rv3[mask] / (rv2 + rv3[mask])
-        ps_prob = all_probs_3d
-        ps_prob[mask, :] = w2.unsqueeze(1) * probs_2d + w3.unsqueeze(1) * probs_3d
+        pc2, pc3, ps_prob = pseudo_label_fuse_ref(logit_2d_teacher, ema3d, mask, hr32["hs_pc_ety"], hr23["hs_pc_ety"],
+                                                  hr_cfg["conf_perc"])
         ps_label = hr_ref.refine_pseudo_labels(ps_prob.amax(1), ps_prob.argmax(1))
     hr23.update({"ac_pc_ety": pc2, "tr_pc_ety": pc3})
     l23 = hr_ref.cr_forward(hr23)

@@ -116,3 +116,55 @@ def test_hr_block_raises_like_reference_when_nothing_corresponds():
     hb = dict(hb, seg_logit=hb["seg_logit"].cuda())
     with pytest.raises(AssertionError):
         HR_Block(cfg["temp_wd_size"], cfg["max_range"], cfg["voxel_size"], cfg["conf_perc"])(ab, at, hb, ht)
+
+
+@pytest.mark.parametrize("cp", [0.9, None])
+@pytest.mark.parametrize("N,C", [(5000, 10), (257, 17), (64, 2)])
+def test_pseudo_label_fuse_matches_oracle(N, C, cp):
+    """lt_pseudo_label_fuse (two kernels) against the oracle's restatement of latte.py:207-236: entropies and confidences
+    to 1e-5, labels identical wherever the two best fused probabilities are further apart than the fp32 noise."""
+    from latte_amd import ops
+    from oracle.step_ref import pseudo_label_fuse_ref
+    g = torch.Generator().manual_seed(N + C)
+    mask = torch.rand(N, generator=g) < 0.4
+    Nf = int(mask.sum())
+    l2 = 3 * torch.randn(Nf, C, generator=g)
+    l3 = 3 * torch.randn(N, C, generator=g)
+    st2 = torch.rand(Nf, generator=g) * (torch.rand(Nf, generator=g) < 0.7)      # 0 = the point has no ST voxel
+    st3 = torch.rand(N, generator=g) * (torch.rand(N, generator=g) < 0.7)
+    want_pc2, want_pc3, prob = pseudo_label_fuse_ref(l2, l3, mask, st2.clone(), st3.clone(), cp)
+    fov_idx = mask.nonzero().squeeze(1).cuda()
+    thr2 = thr3 = None
+    if cp is not None:
+        thr2, thr3 = torch.quantile(st2.cuda(), cp), torch.quantile(st3.cuda(), cp)
+    pc2, pc3, conf, label = ops.pseudo_label_fuse(l2.cuda(), l3.cuda(), fov_idx, st2.cuda(), st3.cuda(), thr2, thr3)
+    assert label.dtype == torch.int32
+    # substituted entries are copies (bit-exact); computed entropies agree to fp32 rounding
+    assert torch.allclose(pc2.cpu(), want_pc2, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(pc3.cpu(), want_pc3, rtol=1e-5, atol=1e-6)
+    sub3 = (st3 != 0) if cp is None else (st3 != 0) & (st3 <= thr3.cpu())
+    assert torch.equal(pc3.cpu()[sub3], st3[sub3])
+    assert torch.allclose(conf.cpu(), prob.amax(1), rtol=1e-5, atol=1e-7)
+    top2 = prob.topk(2, 1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 1e-5
+    assert clear.float().mean() > 0.99
+    assert torch.equal(label.cpu().long()[clear], prob.argmax(1)[clear])
+
+
+def test_pseudo_label_fuse_edge_cases():
+    from latte_amd import ops
+    dev = "cuda"
+    # no point inside the FOV: 3-D teacher alone
+    l3 = torch.randn(100, 6, device=dev)
+    e = torch.zeros(0, device=dev)
+    pc2, pc3, conf, label = ops.pseudo_label_fuse(torch.zeros(0, 6, device=dev), l3, torch.zeros(0, dtype=torch.int64, device=dev),
+                                                  e, torch.zeros(100, device=dev))
+    p = torch.softmax(l3, 1)
+    assert pc2.numel() == 0 and torch.allclose(conf, p.amax(1), rtol=1e-5) and torch.equal(label.long(), p.argmax(1))
+    # empty scan
+    out = ops.pseudo_label_fuse(torch.zeros(0, 6, device=dev), torch.zeros(0, 6, device=dev),
+                                torch.zeros(0, dtype=torch.int64, device=dev), e, e)
+    assert all(o.numel() == 0 for o in out)
+    with pytest.raises(RuntimeError):
+        ops.pseudo_label_fuse(torch.zeros(0, 65, device=dev), torch.zeros(4, 65, device=dev),
+                              torch.zeros(0, dtype=torch.int64, device=dev), e, torch.zeros(4, device=dev))
