@@ -27,12 +27,19 @@ extern "C" int64_t lt_bn_workspace_bytes(int64_t V, int32_t C) {
   return (int64_t)BN_MAX_BLOCKS * 2 * C * 4 + 256;
 }
 
+// A column-reduction op: cols() = the per-column-group constants of a thread (registers), load() = the raw 16-B loads
+// of one row, acc() = the accumulation.  k_col_partial keeps four rows of loads in flight and accumulates in row order.
 struct StatsOp {
   const float* x;
-  __device__ void operator()(int64_t row, int cg, int C, float4& a, float4& b) const {
-    const float4 v = reinterpret_cast<const float4*>(x + row * C)[cg];
-    const float4 s = reinterpret_cast<const float4*>(x)[cg];  // shift = row 0
-    const float dx = v.x - s.x, dy = v.y - s.y, dz = v.z - s.z, dw = v.w - s.w;
+  struct Cols { float4 s; };
+  struct Ld { float4 v; };
+  static constexpr int kLoads = 1;
+  __device__ __forceinline__ Cols cols(int cg) const { return Cols{reinterpret_cast<const float4*>(x)[cg]}; }  // shift = row 0
+  __device__ __forceinline__ Ld load(int64_t row, int cg, int C) const {
+    return Ld{reinterpret_cast<const float4*>(x + row * C)[cg]};
+  }
+  __device__ __forceinline__ void acc(const Ld& l, const Cols& c, float4& a, float4& b) const {
+    const float dx = l.v.x - c.s.x, dy = l.v.y - c.s.y, dz = l.v.z - c.s.z, dw = l.v.w - c.s.w;
     a.x += dx; a.y += dy; a.z += dz; a.w += dw;
     b.x += dx * dx; b.y += dy * dy; b.z += dz * dz; b.w += dw * dw;
   }
@@ -44,44 +51,62 @@ __device__ __forceinline__ float bn_affine(float v, float m, float vr, float g, 
   return __fmaf_rn((v - m) * (1.0f / sqrtf(vr + eps)), g, b);
 }
 
+// MODE 0: no ReLU; 1: ReLU mask from y; 2: mask rebuilt from x (gamma * xhat + beta > 0; no residual was added)
+template <int MODE>
 struct BwdOp {
   const float* dy;
   const float* x;
-  const float* y;  // ReLU mask from y; null: no ReLU, or (gamma != null) mask rebuilt from x
+  const float* y;
   const float* mean;
   const float* var;
   float eps;
-  const float* gamma;  // non-null: rebuild the ReLU mask  gamma * xhat + beta > 0
+  const float* gamma;
   const float* beta;
-  __device__ void operator()(int64_t row, int cg, int C, float4& a, float4& b) const {
-    float4 g = reinterpret_cast<const float4*>(dy + row * C)[cg];
-    if (y) {
-      const float4 yy = reinterpret_cast<const float4*>(y + row * C)[cg];
-      g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
-      g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
+  struct Cols { float4 m, vr, gm, bt; };
+  struct Ld { float4 g, v, yy; };
+  static constexpr int kLoads = MODE == 1 ? 3 : 2;
+  __device__ __forceinline__ Cols cols(int cg) const {
+    Cols c;
+    c.m = reinterpret_cast<const float4*>(mean)[cg];
+    c.vr = reinterpret_cast<const float4*>(var)[cg];
+    c.gm = c.bt = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (MODE == 2) {
+      c.gm = reinterpret_cast<const float4*>(gamma)[cg];
+      c.bt = reinterpret_cast<const float4*>(beta)[cg];
     }
-    const float4 v = reinterpret_cast<const float4*>(x + row * C)[cg];
-    const float4 m = reinterpret_cast<const float4*>(mean)[cg];
-    const float4 vr = reinterpret_cast<const float4*>(var)[cg];
-    if (gamma) {
-      const float4 gm = reinterpret_cast<const float4*>(gamma)[cg];
-      const float4 bt = reinterpret_cast<const float4*>(beta)[cg];
-      g.x = bn_affine(v.x, m.x, vr.x, gm.x, bt.x, eps) > 0.f ? g.x : 0.f;
-      g.y = bn_affine(v.y, m.y, vr.y, gm.y, bt.y, eps) > 0.f ? g.y : 0.f;
-      g.z = bn_affine(v.z, m.z, vr.z, gm.z, bt.z, eps) > 0.f ? g.z : 0.f;
-      g.w = bn_affine(v.w, m.w, vr.w, gm.w, bt.w, eps) > 0.f ? g.w : 0.f;
+    return c;
+  }
+  __device__ __forceinline__ Ld load(int64_t row, int cg, int C) const {
+    Ld l;
+    l.g = reinterpret_cast<const float4*>(dy + row * C)[cg];
+    l.v = reinterpret_cast<const float4*>(x + row * C)[cg];
+    l.yy = MODE == 1 ? reinterpret_cast<const float4*>(y + row * C)[cg] : make_float4(0.f, 0.f, 0.f, 0.f);
+    return l;
+  }
+  __device__ __forceinline__ void acc(const Ld& l, const Cols& c, float4& a, float4& b) const {
+    float4 g = l.g;
+    const float4 v = l.v;
+    if (MODE == 1) {
+      g.x = l.yy.x > 0.f ? g.x : 0.f; g.y = l.yy.y > 0.f ? g.y : 0.f;
+      g.z = l.yy.z > 0.f ? g.z : 0.f; g.w = l.yy.w > 0.f ? g.w : 0.f;
+    }
+    if (MODE == 2) {
+      g.x = bn_affine(v.x, c.m.x, c.vr.x, c.gm.x, c.bt.x, eps) > 0.f ? g.x : 0.f;
+      g.y = bn_affine(v.y, c.m.y, c.vr.y, c.gm.y, c.bt.y, eps) > 0.f ? g.y : 0.f;
+      g.z = bn_affine(v.z, c.m.z, c.vr.z, c.gm.z, c.bt.z, eps) > 0.f ? g.z : 0.f;
+      g.w = bn_affine(v.w, c.m.w, c.vr.w, c.gm.w, c.bt.w, eps) > 0.f ? g.w : 0.f;
     }
     a.x += g.x; a.y += g.y; a.z += g.z; a.w += g.w;
-    b.x += g.x * ((v.x - m.x) * (1.0f / sqrtf(vr.x + eps)));
-    b.y += g.y * ((v.y - m.y) * (1.0f / sqrtf(vr.y + eps)));
-    b.z += g.z * ((v.z - m.z) * (1.0f / sqrtf(vr.z + eps)));
-    b.w += g.w * ((v.w - m.w) * (1.0f / sqrtf(vr.w + eps)));
+    b.x += g.x * ((v.x - c.m.x) * (1.0f / sqrtf(c.vr.x + eps)));
+    b.y += g.y * ((v.y - c.m.y) * (1.0f / sqrtf(c.vr.y + eps)));
+    b.z += g.z * ((v.z - c.m.z) * (1.0f / sqrtf(c.vr.z + eps)));
+    b.w += g.w * ((v.w - c.m.w) * (1.0f / sqrtf(c.vr.w + eps)));
   }
 };
 
 // partial[(blk*2 + which)*C + c]
 template <class Op>
-__global__ __launch_bounds__(BN_BLOCK) void k_col_partial(Op op, int64_t V, int C, float* __restrict__ partial) {
+__global__ __launch_bounds__(BN_BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) void k_col_partial(Op op, int64_t V, int C, float* __restrict__ partial) {
   extern __shared__ float s_red[];  // [rpi][2][C]
   const int cg_n = C / 4;
   const int rpi = BN_BLOCK / cg_n > 0 ? BN_BLOCK / cg_n : 1;
@@ -94,7 +119,20 @@ __global__ __launch_bounds__(BN_BLOCK) void k_col_partial(Op op, int64_t V, int 
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     int64_t r1 = r0 + rows_per_block;
     if (r1 > V) r1 = V;
-    for (int64_t row = r0 + rr; row < r1; row += rpi) op(row, cg, C, a, b);
+    const typename Op::Cols c = op.cols(cg);
+    int64_t row = r0 + rr;
+    for (; row + 3 * (int64_t)rpi < r1; row += 4 * (int64_t)rpi) {
+      typename Op::Ld l[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) l[i] = op.load(row + i * (int64_t)rpi, cg, C);
+      __builtin_amdgcn_sched_barrier(0);  // all loads of the four rows issue before the first accumulate
+#pragma unroll
+      for (int i = 0; i < 4; ++i) op.acc(l[i], c, a, b);
+    }
+    for (; row < r1; row += rpi) {
+      const typename Op::Ld l = op.load(row, cg, C);
+      op.acc(l, c, a, b);
+    }
     float* d = s_red + (int64_t)rr * 2 * C;
     reinterpret_cast<float4*>(d)[cg] = a;
     reinterpret_cast<float4*>(d + C)[cg] = b;
@@ -241,33 +279,70 @@ extern "C" int lt_bn_finalize_sums(void* stats_ws, int64_t V, int32_t C, float* 
   return LT_OK;
 }
 
-__global__ void k_bn_apply(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ var,
-                           const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                           const float* __restrict__ res, int relu, float* __restrict__ y, int64_t n4, int cg_n) {
-  // column group of element e without a 64-bit modulo per element: one modulo per thread, then a wrapped increment
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  const int cstep = (int)(stride % cg_n);
-  int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  int cg = (int)(e % cg_n);
-  for (; e < n4; e += stride, cg = cg + cstep >= cg_n ? cg + cstep - cg_n : cg + cstep) {
-    const float4 v = reinterpret_cast<const float4*>(x)[e];
-    const float4 m = reinterpret_cast<const float4*>(mean)[cg];
-    const float4 vr = reinterpret_cast<const float4*>(var)[cg];
-    const float4 g = reinterpret_cast<const float4*>(gamma)[cg];
-    const float4 b = reinterpret_cast<const float4*>(beta)[cg];
-    float4 o;
-    o.x = bn_affine(v.x, m.x, vr.x, g.x, b.x, eps);
-    o.y = bn_affine(v.y, m.y, vr.y, g.y, b.y, eps);
-    o.z = bn_affine(v.z, m.z, vr.z, g.z, b.z, eps);
-    o.w = bn_affine(v.w, m.w, vr.w, g.w, b.w, eps);
-    if (res) {
-      const float4 rr = reinterpret_cast<const float4*>(res)[e];
-      o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
+// grid of the two elementwise kernels: the launch's thread count is a multiple of the number of column groups, so a
+// thread keeps ONE column group for all its elements (its mean / var / gamma / beta sit in registers), and about four
+// float4 elements per thread so that four loads are in flight
+static int bn_ew_grid(int64_t n4, int cg_n) {
+  int64_t g = (n4 + 1023) / 1024;
+  if (g > 2048) g = 2048;
+  if (g < 512) {
+    g = (n4 + 255) / 256;
+    if (g > 512) g = 512;
+  }
+  if (g < 1) g = 1;
+  int a = cg_n, b = 256;
+  while (b) { const int t = a % b; a = b; b = t; }
+  const int q = cg_n / a;  // smallest block count whose thread count is a multiple of cg_n
+  return (int)((g + q - 1) / q * q);
+}
+
+__device__ __forceinline__ float4 bn_apply4(float4 v, float4 m, float4 vr, float4 g, float4 b, float eps) {
+  float4 o;
+  o.x = bn_affine(v.x, m.x, vr.x, g.x, b.x, eps);
+  o.y = bn_affine(v.y, m.y, vr.y, g.y, b.y, eps);
+  o.z = bn_affine(v.z, m.z, vr.z, g.z, b.z, eps);
+  o.w = bn_affine(v.w, m.w, vr.w, g.w, b.w, eps);
+  return o;
+}
+
+template <bool RES>
+__global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ x, const float* __restrict__ mean,
+                                                  const float* __restrict__ var, const float* __restrict__ gamma,
+                                                  const float* __restrict__ beta, float eps,
+                                                  const float* __restrict__ res, int relu, float* __restrict__ y,
+                                                  int64_t n4, int cg_n) {
+  const int64_t stride = (int64_t)gridDim.x * 256;  // a multiple of cg_n (bn_ew_grid)
+  int64_t e = blockIdx.x * (int64_t)256 + threadIdx.x;
+  const int cg = (int)(e % cg_n);
+  const float4 m = reinterpret_cast<const float4*>(mean)[cg];
+  const float4 vr = reinterpret_cast<const float4*>(var)[cg];
+  const float4 g = reinterpret_cast<const float4*>(gamma)[cg];
+  const float4 b = reinterpret_cast<const float4*>(beta)[cg];
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  const float4* r4 = reinterpret_cast<const float4*>(res);
+  float4* y4 = reinterpret_cast<float4*>(y);
+  for (; e + 3 * stride < n4; e += 4 * stride) {
+    float4 v[4], r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = x4[e + i * stride];
+    if (RES) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) r[i] = r4[e + i * stride];
     }
-    if (relu) {
-      o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+    __builtin_amdgcn_sched_barrier(0);  // all loads issue before the first use
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float4 o = bn_apply4(v[i], m, vr, g, b, eps);
+      if (RES) { o.x += r[i].x; o.y += r[i].y; o.z += r[i].z; o.w += r[i].w; }
+      if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+      y4[e + i * stride] = o;
     }
-    reinterpret_cast<float4*>(y)[e] = o;
+  }
+  for (; e < n4; e += stride) {
+    float4 o = bn_apply4(x4[e], m, vr, g, b, eps);
+    if (RES) { const float4 rr = r4[e]; o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w; }
+    if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+    y4[e] = o;
   }
 }
 
@@ -278,8 +353,13 @@ extern "C" int lt_bn_apply(const float* x, const float* mean, const float* var, 
   if (rc) return rc;
   LT_REQUIRE(x && mean && var && gamma && beta && y, LT_ERR_ARG, "lt_bn_apply: null pointer");
   const int64_t n4 = V * (C / 4);
-  hipLaunchKernelGGL(k_bn_apply, dim3(lt_grid(n4, 256)), dim3(256), 0, stream, x, mean, var, gamma, beta, eps, residual,
-                     relu, y, n4, C / 4);
+  const dim3 grid(bn_ew_grid(n4, C / 4));
+  if (residual)
+    hipLaunchKernelGGL(k_bn_apply<true>, grid, dim3(256), 0, stream, x, mean, var, gamma, beta, eps, residual, relu, y, n4,
+                       C / 4);
+  else
+    hipLaunchKernelGGL(k_bn_apply<false>, grid, dim3(256), 0, stream, x, mean, var, gamma, beta, eps, residual, relu, y,
+                       n4, C / 4);
   LT_LAUNCH_CHECK();
   return LT_OK;
 }
@@ -295,59 +375,100 @@ extern "C" int lt_bn_bwd_reduce(const float* dy, const float* x, const float* y,
   LT_REQUIRE(ws_bytes >= lt_bn_workspace_bytes(V, C), LT_ERR_WORKSPACE, "lt_bn_bwd_reduce: workspace too small");
   const int nb = bn_blocks(V, C);
   const int cg = C / 4, rpi = BN_BLOCK / cg > 0 ? BN_BLOCK / cg : 1;
-  BwdOp op{dy, x, relu == 1 ? y : nullptr, mean, var, eps, relu == 2 ? gamma : nullptr, relu == 2 ? beta : nullptr};
-  hipLaunchKernelGGL(k_col_partial<BwdOp>, dim3(nb), dim3(BN_BLOCK), (size_t)rpi * 2 * C * 4, stream, op, V, C,
-                     (float*)ws);
+  const size_t lds = (size_t)rpi * 2 * C * 4;
+  if (relu == 1) {
+    BwdOp<1> op{dy, x, y, mean, var, eps, gamma, beta};
+    hipLaunchKernelGGL(k_col_partial<BwdOp<1>>, dim3(nb), dim3(BN_BLOCK), lds, stream, op, V, C, (float*)ws);
+  } else if (relu == 2) {
+    BwdOp<2> op{dy, x, y, mean, var, eps, gamma, beta};
+    hipLaunchKernelGGL(k_col_partial<BwdOp<2>>, dim3(nb), dim3(BN_BLOCK), lds, stream, op, V, C, (float*)ws);
+  } else {
+    BwdOp<0> op{dy, x, y, mean, var, eps, gamma, beta};
+    hipLaunchKernelGGL(k_col_partial<BwdOp<0>>, dim3(nb), dim3(BN_BLOCK), lds, stream, op, V, C, (float*)ws);
+  }
   LT_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_sum_partials, dim3(C), dim3(64), 0, stream, (const float*)ws, nb, C, sum_g, sum_gx);
   LT_LAUNCH_CHECK();
   return LT_OK;
 }
 
-__global__ void k_bn_bwd_apply(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y,
-                               const float* __restrict__ mean, const float* __restrict__ var,
-                               const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                               const float* __restrict__ sum_g, const float* __restrict__ sum_gx,
-                               float* __restrict__ dx, float* __restrict__ dres, int64_t n4, int cg_n, float inv_v) {
-  // beta != null: the ReLU mask is rebuilt from x (y is null then)
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  const int cstep = (int)(stride % cg_n);
-  int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  int cg = (int)(e % cg_n);
-  for (; e < n4; e += stride, cg = cg + cstep >= cg_n ? cg + cstep - cg_n : cg + cstep) {
-    float4 g = reinterpret_cast<const float4*>(dy)[e];
-    if (y) {
-      const float4 yy = reinterpret_cast<const float4*>(y)[e];
-      g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
-      g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
+// one float4 of the BatchNorm backward: g = dy under the ReLU mask (from y, or rebuilt from x when bt is given), then
+// dx = gamma * rstd * (g - sum_g/V - xhat * sum_gx/V)
+struct BnBwdCols {
+  float4 m, vr, gm, bt, sg, sx;
+};
+template <bool MASK_Y, bool MASK_X>
+__device__ __forceinline__ float4 bn_bwd_mask4(float4 g, float4 yy, float4 v, const BnBwdCols& c, float eps) {
+  if (MASK_Y) {
+    g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
+    g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
+  }
+  if (MASK_X) {
+    g.x = bn_affine(v.x, c.m.x, c.vr.x, c.gm.x, c.bt.x, eps) > 0.f ? g.x : 0.f;
+    g.y = bn_affine(v.y, c.m.y, c.vr.y, c.gm.y, c.bt.y, eps) > 0.f ? g.y : 0.f;
+    g.z = bn_affine(v.z, c.m.z, c.vr.z, c.gm.z, c.bt.z, eps) > 0.f ? g.z : 0.f;
+    g.w = bn_affine(v.w, c.m.w, c.vr.w, c.gm.w, c.bt.w, eps) > 0.f ? g.w : 0.f;
+  }
+  return g;
+}
+__device__ __forceinline__ float4 bn_bwd_dx4(float4 g, float4 v, const BnBwdCols& c, float eps, float inv_v) {
+  float4 o;
+  float rs;
+  rs = 1.0f / sqrtf(c.vr.x + eps); o.x = c.gm.x * rs * (g.x - c.sg.x * inv_v - (v.x - c.m.x) * rs * c.sx.x * inv_v);
+  rs = 1.0f / sqrtf(c.vr.y + eps); o.y = c.gm.y * rs * (g.y - c.sg.y * inv_v - (v.y - c.m.y) * rs * c.sx.y * inv_v);
+  rs = 1.0f / sqrtf(c.vr.z + eps); o.z = c.gm.z * rs * (g.z - c.sg.z * inv_v - (v.z - c.m.z) * rs * c.sx.z * inv_v);
+  rs = 1.0f / sqrtf(c.vr.w + eps); o.w = c.gm.w * rs * (g.w - c.sg.w * inv_v - (v.w - c.m.w) * rs * c.sx.w * inv_v);
+  return o;
+}
+
+// MASK_Y: ReLU mask from y; MASK_X: mask rebuilt from x (no residual was added, y is not kept); neither: no ReLU.
+// dx and/or dres may be null (a residual branch only needs the masked gradient).
+template <bool MASK_Y, bool MASK_X>
+__global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ dy, const float* __restrict__ x,
+                                                      const float* __restrict__ y, const float* __restrict__ mean,
+                                                      const float* __restrict__ var, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float eps,
+                                                      const float* __restrict__ sum_g, const float* __restrict__ sum_gx,
+                                                      float* __restrict__ dx, float* __restrict__ dres, int64_t n4,
+                                                      int cg_n, float inv_v) {
+  const int64_t stride = (int64_t)gridDim.x * 256;  // a multiple of cg_n (bn_ew_grid)
+  int64_t e = blockIdx.x * (int64_t)256 + threadIdx.x;
+  const int cg = (int)(e % cg_n);
+  BnBwdCols c;
+  c.m = reinterpret_cast<const float4*>(mean)[cg];
+  c.vr = reinterpret_cast<const float4*>(var)[cg];
+  c.gm = reinterpret_cast<const float4*>(gamma)[cg];
+  c.bt = MASK_X ? reinterpret_cast<const float4*>(beta)[cg] : make_float4(0.f, 0.f, 0.f, 0.f);
+  c.sg = reinterpret_cast<const float4*>(sum_g)[cg];
+  c.sx = reinterpret_cast<const float4*>(sum_gx)[cg];
+  const float4* dy4 = reinterpret_cast<const float4*>(dy);
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  const float4* y4 = reinterpret_cast<const float4*>(y);
+  float4* dx4 = reinterpret_cast<float4*>(dx);
+  float4* dr4 = reinterpret_cast<float4*>(dres);
+  const bool need_x = MASK_X || dx != nullptr;
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (; e + 3 * stride < n4; e += 4 * stride) {
+    float4 g[4], v[4], yy[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) g[i] = dy4[e + i * stride];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = need_x ? x4[e + i * stride] : z;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) yy[i] = MASK_Y ? y4[e + i * stride] : z;
+    __builtin_amdgcn_sched_barrier(0);  // all loads issue before the first use
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 gi = bn_bwd_mask4<MASK_Y, MASK_X>(g[i], yy[i], v[i], c, eps);
+      if (dres) dr4[e + i * stride] = gi;
+      if (dx) dx4[e + i * stride] = bn_bwd_dx4(gi, v[i], c, eps, inv_v);
     }
-    if (beta) {
-      const float4 v = reinterpret_cast<const float4*>(x)[e];
-      const float4 m = reinterpret_cast<const float4*>(mean)[cg];
-      const float4 vr = reinterpret_cast<const float4*>(var)[cg];
-      const float4 gm = reinterpret_cast<const float4*>(gamma)[cg];
-      const float4 bt = reinterpret_cast<const float4*>(beta)[cg];
-      g.x = bn_affine(v.x, m.x, vr.x, gm.x, bt.x, eps) > 0.f ? g.x : 0.f;
-      g.y = bn_affine(v.y, m.y, vr.y, gm.y, bt.y, eps) > 0.f ? g.y : 0.f;
-      g.z = bn_affine(v.z, m.z, vr.z, gm.z, bt.z, eps) > 0.f ? g.z : 0.f;
-      g.w = bn_affine(v.w, m.w, vr.w, gm.w, bt.w, eps) > 0.f ? g.w : 0.f;
-    }
-    if (dres) reinterpret_cast<float4*>(dres)[e] = g;
-    if (dx) {
-      const float4 v = reinterpret_cast<const float4*>(x)[e];
-      const float4 m = reinterpret_cast<const float4*>(mean)[cg];
-      const float4 vr = reinterpret_cast<const float4*>(var)[cg];
-      const float4 gm = reinterpret_cast<const float4*>(gamma)[cg];
-      const float4 sg = reinterpret_cast<const float4*>(sum_g)[cg];
-      const float4 sx = reinterpret_cast<const float4*>(sum_gx)[cg];
-      float4 o;
-      float rs;
-      rs = 1.0f / sqrtf(vr.x + eps); o.x = gm.x * rs * (g.x - sg.x * inv_v - (v.x - m.x) * rs * sx.x * inv_v);
-      rs = 1.0f / sqrtf(vr.y + eps); o.y = gm.y * rs * (g.y - sg.y * inv_v - (v.y - m.y) * rs * sx.y * inv_v);
-      rs = 1.0f / sqrtf(vr.z + eps); o.z = gm.z * rs * (g.z - sg.z * inv_v - (v.z - m.z) * rs * sx.z * inv_v);
-      rs = 1.0f / sqrtf(vr.w + eps); o.w = gm.w * rs * (g.w - sg.w * inv_v - (v.w - m.w) * rs * sx.w * inv_v);
-      reinterpret_cast<float4*>(dx)[e] = o;
-    }
+  }
+  for (; e < n4; e += stride) {
+    const float4 v = need_x ? x4[e] : z;
+    const float4 gi = bn_bwd_mask4<MASK_Y, MASK_X>(dy4[e], MASK_Y ? y4[e] : z, v, c, eps);
+    if (dres) dr4[e] = gi;
+    if (dx) dx4[e] = bn_bwd_dx4(gi, v, c, eps, inv_v);
   }
 }
 
@@ -360,8 +481,17 @@ extern "C" int lt_bn_bwd_apply(const float* dy, const float* x, const float* y, 
   LT_REQUIRE(dy && x && mean && var && gamma && sum_g && sum_gx && (relu != 1 || y) && (relu != 2 || beta), LT_ERR_ARG,
              "lt_bn_bwd_apply: null pointer");
   const int64_t n4 = V * (C / 4);
-  hipLaunchKernelGGL(k_bn_bwd_apply, dim3(lt_grid(n4, 256)), dim3(256), 0, stream, dy, x, relu == 1 ? y : nullptr, mean,
-                     var, gamma, relu == 2 ? beta : nullptr, eps, sum_g, sum_gx, dx, dres, n4, C / 4, 1.0f / (float)V);
+  const dim3 grid(bn_ew_grid(n4, C / 4));
+  const float inv_v = 1.0f / (float)V;
+  if (relu == 1)
+    hipLaunchKernelGGL((k_bn_bwd_apply<true, false>), grid, dim3(256), 0, stream, dy, x, y, mean, var, gamma, beta, eps, sum_g,
+                       sum_gx, dx, dres, n4, C / 4, inv_v);
+  else if (relu == 2)
+    hipLaunchKernelGGL((k_bn_bwd_apply<false, true>), grid, dim3(256), 0, stream, dy, x, y, mean, var, gamma, beta, eps, sum_g,
+                       sum_gx, dx, dres, n4, C / 4, inv_v);
+  else
+    hipLaunchKernelGGL((k_bn_bwd_apply<false, false>), grid, dim3(256), 0, stream, dy, x, y, mean, var, gamma, beta, eps,
+                       sum_g, sum_gx, dx, dres, n4, C / 4, inv_v);
   LT_LAUNCH_CHECK();
   return LT_OK;
 }
