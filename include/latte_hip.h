@@ -158,6 +158,9 @@ int lt_bn_stats(const float* x, int64_t V, int32_t C, void* ws, int64_t ws_bytes
                 lt_stream_t stream);
 /* mean / biased variance from the column sums lt_spconv_plan_fwd_stats left in stats_ws (V = Vout, C = Cout of that call) */
 int lt_bn_finalize_sums(void* stats_ws, int64_t V, int32_t C, float* mean, float* var, lt_stream_t stream);
+/* relu: 0 = y = bn(x) + residual;  1 = y = relu(bn(x) + residual)  (ResidualBlock, basic_blocks.py:72-75);
+ * 3 = y = relu(bn(x)) + residual: the sum after the activation -- the point branch of SPVCNN,
+ * z.F + point_transforms(z.F) (latte/models/spvcnn.py:95-111 and its forward).  residual may be NULL (relu 0 / 1). */
 int lt_bn_apply(const float* x, const float* mean, const float* var, const float* gamma, const float* beta,
                 float eps, const float* residual, int32_t relu, float* y, int64_t V, int32_t C,
                 lt_stream_t stream);

@@ -321,6 +321,8 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ x, c
   const float4* x4 = reinterpret_cast<const float4*>(x);
   const float4* r4 = reinterpret_cast<const float4*>(res);
   float4* y4 = reinterpret_cast<float4*>(y);
+  const bool post = (relu & 2) != 0;  // the residual is added after the ReLU
+  relu &= 1;
   for (; e + 3 * stride < n4; e += 4 * stride) {
     float4 v[4], r[4];
 #pragma unroll
@@ -333,15 +335,19 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ x, c
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       float4 o = bn_apply4(v[i], m, vr, g, b, eps);
-      if (RES) { o.x += r[i].x; o.y += r[i].y; o.z += r[i].z; o.w += r[i].w; }
+      if (RES && !post) { o.x += r[i].x; o.y += r[i].y; o.z += r[i].z; o.w += r[i].w; }
       if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+      if (RES && post) { o.x += r[i].x; o.y += r[i].y; o.z += r[i].z; o.w += r[i].w; }
       y4[e + i * stride] = o;
     }
   }
   for (; e < n4; e += stride) {
     float4 o = bn_apply4(x4[e], m, vr, g, b, eps);
-    if (RES) { const float4 rr = r4[e]; o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w; }
+    float4 rr = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (RES) rr = r4[e];
+    if (RES && !post) { o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w; }
     if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+    if (RES && post) { o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w; }
     y4[e] = o;
   }
 }
@@ -352,6 +358,8 @@ extern "C" int lt_bn_apply(const float* x, const float* mean, const float* var, 
   int rc = check_vc("lt_bn_apply", V, C);
   if (rc) return rc;
   LT_REQUIRE(x && mean && var && gamma && beta && y, LT_ERR_ARG, "lt_bn_apply: null pointer");
+  LT_REQUIRE(relu == 0 || relu == 1 || (relu == 3 && residual), LT_ERR_ARG,
+             "lt_bn_apply: relu=%d not in {0,1,3} (3 needs a residual)", relu);
   const int64_t n4 = V * (C / 4);
   const dim3 grid(bn_ew_grid(n4, C / 4));
   if (residual)

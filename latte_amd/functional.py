@@ -185,16 +185,19 @@ def sparse_conv(feats, weight, kmap: KernelMap, transposed: bool = False, wcache
 
 
 class _BatchNorm(Function):
-    """BN with batch statistics, optional fused residual add and ReLU: y = relu(bn(x) + residual)."""
+    """BN with batch statistics, optional fused residual add and ReLU: y = relu(bn(x) + residual); post_add (with relu and
+    a residual): y = relu(bn(x)) + residual, the sum after the activation (the point branch of SPVCNN)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, eps, relu, stats_out):
+    def forward(ctx, x, gamma, beta, residual, eps, relu, stats_out, post_add=False):
         mean, var = ops.bn_stats(x)
-        y = ops.bn_apply(x, mean, var, gamma, beta, eps, residual=residual, relu=relu)
-        ctx.eps, ctx.relu = eps, relu
+        post_add = bool(post_add and relu and residual is not None)
+        y = ops.bn_apply(x, mean, var, gamma, beta, eps, residual=residual, relu=relu, post_add=post_add)
+        ctx.eps, ctx.relu, ctx.post_add = eps, relu, post_add
         ctx.has_res = residual is not None
-        # ReLU mask in the backward: from y when a residual was added, otherwise rebuilt from x (y is not read again)
-        ctx.save_for_backward(x, y if (relu and residual is not None) else None, mean, var, gamma, beta)
+        # ReLU mask in the backward: from y when a residual was added before the ReLU, otherwise rebuilt from x (y is not
+        # read again; with post_add y is not the activation's output, so it cannot serve as the mask)
+        ctx.save_for_backward(x, y if (relu and residual is not None and not post_add) else None, mean, var, gamma, beta)
         if stats_out is not None:
             stats_out.append((mean, var))
         return y
@@ -205,9 +208,14 @@ class _BatchNorm(Function):
         dy = dy.contiguous()
         need_dx = ctx.needs_input_grad[0]
         need_dres = ctx.has_res and ctx.needs_input_grad[3]
+        if ctx.post_add:
+            # the residual bypasses the ReLU: its gradient is dy itself
+            dx, dgamma, dbeta, _ = ops.bn_bwd(dy, x, None, mean, var, gamma, ctx.eps, True, need_dx=need_dx,
+                                              need_dres=False, beta=beta)
+            return dx, dgamma, dbeta, (dy if need_dres else None), None, None, None, None
         dx, dgamma, dbeta, dres = ops.bn_bwd(dy, x, y, mean, var, gamma, ctx.eps, ctx.relu, need_dx=need_dx,
                                              need_dres=need_dres, beta=beta)
-        return dx, dgamma, dbeta, dres, None, None, None
+        return dx, dgamma, dbeta, dres, None, None, None, None
 
 
 class _ConvBN(Function):
@@ -260,11 +268,11 @@ def conv_bn(feats, weight, gamma, beta, kmap: KernelMap, transposed=False, resid
                          float(eps), wcache)
 
 
-def batch_norm(x, gamma, beta, eps=1e-5, residual=None, relu=False, stats_out=None):
+def batch_norm(x, gamma, beta, eps=1e-5, residual=None, relu=False, stats_out=None, post_add=False):
     if x.shape[0] * 1 == 1:
         # same refusal as torch.nn.functional.batch_norm in training mode
         raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(x.shape)}")
-    return _BatchNorm.apply(x, gamma, beta, residual, float(eps), bool(relu), stats_out)
+    return _BatchNorm.apply(x, gamma, beta, residual, float(eps), bool(relu), stats_out, bool(post_add))
 
 
 class _Voxelize(Function):

@@ -267,7 +267,8 @@ def bn_stats(x: torch.Tensor):
     return mean, var
 
 
-def bn_apply(x, mean, var, gamma, beta, eps: float, residual=None, relu: bool = False, out=None):
+def bn_apply(x, mean, var, gamma, beta, eps: float, residual=None, relu: bool = False, out=None, post_add: bool = False):
+    """y = relu?(bn(x) + residual); post_add (with relu and a residual): y = relu(bn(x)) + residual."""
     x = _chk(x, torch.float32, "bn_apply x")
     V, C = x.shape
     y = torch.empty_like(x) if out is None else out
@@ -275,8 +276,8 @@ def bn_apply(x, mean, var, gamma, beta, eps: float, residual=None, relu: bool = 
         residual = _chk(residual, torch.float32, "bn_apply residual")
         assert residual.shape == x.shape
     _lib.call("lt_bn_apply", _p(x), _p(mean), _p(var), _p(_chk(gamma.detach(), torch.float32, "gamma")),
-              _p(_chk(beta.detach(), torch.float32, "beta")), float(eps), _p(residual), int(relu), _p(y), V, C,
-              _stream())
+              _p(_chk(beta.detach(), torch.float32, "beta")), float(eps), _p(residual),
+              3 if (post_add and relu and residual is not None) else int(bool(relu)), _p(y), V, C, _stream())
     return y
 
 

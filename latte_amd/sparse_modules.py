@@ -151,11 +151,13 @@ class BatchNorm(nn.BatchNorm1d):
     """BatchNorm1d over SparseTensor.F.  Batch statistics (training mode or track_running_stats=False, which is what
     configure_model_norm forces: latte/common/utils/ema_util.py:26-29) run in the HIP kernels."""
 
-    def bn_feats(self, feats, residual=None, relu=False):
+    def bn_feats(self, feats, residual=None, relu=False, post_add=False):
+        """relu?(bn(feats) + residual); post_add: relu(bn(feats)) + residual (the sum after the activation)."""
         use_batch = self.training or not self.track_running_stats or self.running_mean is None
         if use_batch:
             stats = [] if (self.training and self.track_running_stats and self.running_mean is not None) else None
-            y = LF.batch_norm(feats, self.weight, self.bias, self.eps, residual=residual, relu=relu, stats_out=stats)
+            y = LF.batch_norm(feats, self.weight, self.bias, self.eps, residual=residual, relu=relu, stats_out=stats,
+                              post_add=post_add)
             if stats:
                 mean, var = stats[0]
                 n = feats.shape[0]
@@ -169,11 +171,13 @@ class BatchNorm(nn.BatchNorm1d):
         # inference statistics: same HIP apply kernel with the running estimates (gradients flow through torch ops)
         if torch.is_grad_enabled() and (feats.requires_grad or self.weight.requires_grad):
             y = (feats - self.running_mean) * torch.rsqrt(self.running_var + self.eps) * self.weight + self.bias
+            if post_add and relu and residual is not None:
+                return torch.relu(y) + residual
             if residual is not None:
                 y = y + residual
             return torch.relu(y) if relu else y
         return ops.bn_apply(feats, self.running_mean, self.running_var, self.weight, self.bias, self.eps,
-                            residual=residual, relu=relu)
+                            residual=residual, relu=relu, post_add=post_add)
 
     def forward(self, input):
         if isinstance(input, SparseTensor):

@@ -125,13 +125,14 @@ class SPVCNN(nn.Module):
         x = _conv_bn(self.stem, x, 0, relu=True)
         return _conv_bn(self.stem, x, 3, relu=True)
 
-    def _pt(self, i: int, f: torch.Tensor) -> torch.Tensor:
-        """point_transforms[i] = Linear -> BatchNorm1d -> ReLU (latte/models/spvcnn.py:95-111); the GEMM stays in
-        torch/hipBLASLt, BN(batch stats)+ReLU is the fused HIP kernel."""
+    def _pt(self, i: int, f: torch.Tensor, add_to: torch.Tensor) -> torch.Tensor:
+        """add_to + point_transforms[i](f), point_transforms[i] = Linear -> BatchNorm1d -> ReLU
+        (latte/models/spvcnn.py:95-111); the GEMM stays in torch/hipBLASLt, BN(batch stats) + ReLU + the sum with the
+        devoxelized features is one HIP kernel."""
         seq = self.point_transforms[i]
         if not f.is_cuda:
-            return seq(f)
-        return seq[1].bn_feats(seq[0](f), relu=True)
+            return add_to + seq(f)
+        return seq[1].bn_feats(seq[0](f), residual=add_to, relu=True, post_add=True)
 
     def _up(self, up, y, skip):
         y = up[0](y)
@@ -192,21 +193,21 @@ class SPVCNN(nn.Module):
         x3 = self.stage3(x2)
         x4 = self.stage4(x3)
         z1 = voxel_to_point(x4, z0)
-        z1.F = z1.F + self._pt(0, z0.F)
+        z1.F = self._pt(0, z0.F, z1.F)
 
         y1 = point_to_voxel(x4, z1)
         y1.F = self.dropout(y1.F)
         y1 = self._up(self.up1, y1, x3)
         y2 = self._up(self.up2, y1, x2)
         z2 = voxel_to_point(y2, z1)
-        z2.F = z2.F + self._pt(1, z1.F)
+        z2.F = self._pt(1, z1.F, z2.F)
 
         y3 = point_to_voxel(y2, z2)
         y3.F = self.dropout(y3.F)
         y3 = self._up(self.up3, y3, x1)
         y4 = self._up(self.up4, y3, x0)
         z3 = voxel_to_point(y4, z2)
-        z3.F = z3.F + self._pt(2, z2.F)
+        z3.F = self._pt(2, z2.F, z3.F)
         return z3.F
 
 

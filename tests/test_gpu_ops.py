@@ -442,3 +442,43 @@ def test_csr_scatter_kernels_match_atomic_kernels(scans_small):
         m = idx8[:, k] >= 0
         want.index_add_(0, idx8[m, k].long(), (w8[m, k].double().unsqueeze(1) * gout[m].double()))
     assert rel_err(b.cpu(), want) < 1e-6 and rel_err(a.cpu(), want) < 1e-6
+
+
+@pytest.mark.parametrize("V,C", [(5000, 32), (777, 96), (33, 256)])
+def test_batch_norm_post_activation_add(V, C):
+    """relu(bn(x)) + r in one kernel (lt_bn_apply relu = 3: the point branch of SPVCNN, z.F + point_transforms(z.F))
+    against the two-step form relu(bn(x)) then a torch add: output and every gradient bitwise (same kernels for the BN
+    part, one fp32 add either way); the gradient of r is dy itself."""
+    from latte_amd import functional as LF
+    g = torch.Generator().manual_seed(V + C)
+    x = torch.randn(V, C, generator=g).cuda().requires_grad_(True)
+    r = torch.randn(V, C, generator=g).cuda().requires_grad_(True)
+    gamma = (torch.rand(C, generator=g) + 0.5).cuda().requires_grad_(True)
+    beta = (0.3 * torch.randn(C, generator=g)).cuda().requires_grad_(True)
+    dy = torch.randn(V, C, generator=g).cuda()
+    y_two = LF.batch_norm(x, gamma, beta, 1e-5, relu=True) + r
+    g_two = torch.autograd.grad(y_two, [x, gamma, beta, r], dy)
+    y_one = LF.batch_norm(x, gamma, beta, 1e-5, residual=r, relu=True, post_add=True)
+    g_one = torch.autograd.grad(y_one, [x, gamma, beta, r], dy)
+    assert torch.equal(y_one, y_two)
+    for a, b in zip(g_one, g_two):
+        assert torch.equal(a, b)
+    assert torch.equal(g_one[3], dy)
+    # and against plain torch
+    xh = (x - x.mean(0)) / torch.sqrt(x.var(0, unbiased=False) + 1e-5)
+    want = torch.relu(xh * gamma + beta) + r
+    assert torch.allclose(y_one, want, rtol=1e-4, atol=1e-5)
+
+
+def test_bn_apply_rejects_unknown_relu_mode():
+    from latte_amd import _lib, ops
+    x = torch.randn(64, 16, device="cuda")
+    m, v = ops.bn_stats(x)
+    one = torch.ones(16, device="cuda")
+    y = torch.empty_like(x)
+    with pytest.raises(RuntimeError):
+        _lib.call("lt_bn_apply", ops._p(x), ops._p(m), ops._p(v), ops._p(one), ops._p(one), 1e-5, None, 3, ops._p(y), 64, 16,
+                  ops._stream())       # 3 needs a residual
+    with pytest.raises(RuntimeError):
+        _lib.call("lt_bn_apply", ops._p(x), ops._p(m), ops._p(v), ops._p(one), ops._p(one), 1e-5, None, 2, ops._p(y), 64, 16,
+                  ops._stream())
