@@ -275,6 +275,32 @@ def batch_norm(x, gamma, beta, eps=1e-5, residual=None, relu=False, stats_out=No
     return _BatchNorm.apply(x, gamma, beta, residual, float(eps), bool(relu), stats_out, bool(post_add))
 
 
+class _GatherRows(Function):
+    """x[idx] (rows).  torch's own backward of advanced indexing is index_put_(accumulate=True): a sort of the indices
+    plus a segmented kernel, ~170 us at 209 k x 16; an index_add_ into zeros is ~15 us (float atomics: the order of the
+    2-3 addends of a row is not fixed -- the same run-to-run noise the step's other index_adds already have)."""
+
+    @staticmethod
+    def forward(ctx, x, idx):
+        ctx.save_for_backward(idx)
+        ctx.n = x.shape[0]
+        return x.index_select(0, idx)
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        out = torch.zeros((ctx.n,) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
+        out.index_add_(0, idx, g.contiguous())
+        return out, None
+
+
+def gather_rows(x: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """x[idx] for an int64 row index vector, with a cheap backward."""
+    if not (x.requires_grad and torch.is_grad_enabled()):
+        return x[idx]
+    return _GatherRows.apply(x, idx)
+
+
 class _Voxelize(Function):
     @staticmethod
     def forward(ctx, feats, idx, counts, csr):

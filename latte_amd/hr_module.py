@@ -26,6 +26,7 @@ import torch.nn.functional as F
 from torch.autograd import Function
 
 from . import ops
+from .functional import gather_rows
 
 __all__ = ["HR_Block", "CR_Block", "prob_2_entropy", "refine_ety"]
 
@@ -211,7 +212,7 @@ class HR_Block(nn.Module):
         split = lambda t: list(torch.split(t, per_anchor, 0))
         tr_logits_all = tr_voxel_probs[t_sel_l]
         out = _HRResult({
-            "ac_logits": split(ac_voxel_probs[a_sel_l]),
+            "ac_logits": split(gather_rows(ac_voxel_probs, a_sel_l)),
             "ac_voxels": split(vox),
             "tr_logits": split(tr_logits_all),
             "tr_voxels": split(vox.clone()),

@@ -19,6 +19,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
+from .functional import gather_rows
 from .hr_module import CR_Block, HR_Block
 from .spvcnn import inverse_to_all
 
@@ -331,7 +332,7 @@ class LatteStep:
                 geo23 = self.hr.geometry(a2, "2D", h3, "3D")
                 geo32 = self.hr.geometry(a3, "3D", h2, "2D")
         preds_3d = self.model(batch)
-        preds_3d["seg_logit"] = preds_3d["seg_logit"][tab["inv_all"]]
+        preds_3d["seg_logit"] = gather_rows(preds_3d["seg_logit"], tab["inv_all"])
         self._tick("student_fwd")
         if late_geo:
             main.wait_stream(side)

@@ -482,3 +482,25 @@ def test_bn_apply_rejects_unknown_relu_mode():
     with pytest.raises(RuntimeError):
         _lib.call("lt_bn_apply", ops._p(x), ops._p(m), ops._p(v), ops._p(one), ops._p(one), 1e-5, None, 2, ops._p(y), 64, 16,
                   ops._stream())
+
+
+def test_gather_rows_backward_matches_torch_indexing():
+    """functional.gather_rows: same forward as x[idx]; the backward (index_add_ into zeros) equals torch's
+    index_put_(accumulate=True) up to the order of the few addends of a row."""
+    from latte_amd.functional import gather_rows
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(3000, 16, generator=g).cuda().requires_grad_(True)
+    idx = torch.randint(0, 3000, (7000,), generator=g).cuda()
+    dy = torch.randn(7000, 16, generator=g).cuda()
+    y = gather_rows(x, idx)
+    assert torch.equal(y, x[idx])
+    (got,) = torch.autograd.grad(y, x, dy)
+    (want,) = torch.autograd.grad(x[idx], x, dy)
+    assert torch.allclose(got, want, rtol=1e-5, atol=1e-6)
+    # unique indices (the matched ST voxels): no accumulation at all, bitwise
+    perm = torch.randperm(3000, generator=g)[:1000].cuda()
+    (got,) = torch.autograd.grad(gather_rows(x, perm), x, dy[:1000])
+    (want,) = torch.autograd.grad(x[perm], x, dy[:1000])
+    assert torch.equal(got, want)
+    with torch.no_grad():
+        assert torch.equal(gather_rows(x, idx), x[idx])
