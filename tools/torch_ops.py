@@ -31,11 +31,11 @@ def main():
         step.step(batch)
     torch.cuda.synchronize()
     from torch.profiler import ProfilerActivity, profile
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
         step.step(batch)
         torch.cuda.synchronize()
     agg = collections.defaultdict(lambda: [0, 0.0])
-    for ev in prof.key_averages(group_by_stack_n=16):
+    for ev in prof.key_averages(group_by_input_shape=True):
         t = ev.self_device_time_total
         if not ev.key.startswith("aten::") or t <= 0:
             continue
@@ -44,8 +44,8 @@ def main():
             if "latte_amd" in fr and "site-packages" not in fr:
                 where = fr.strip().replace(ROOT + "/", "")
                 break
-        if where == "?" and ev.stack:
-            where = "autograd: " + " <- ".join(f.strip().split("/")[-1] for f in ev.stack[:2])
+        if where == "?":
+            where = str(ev.input_shapes)[:120]
         k = (ev.key, where)
         agg[k][0] += ev.count
         agg[k][1] += t
