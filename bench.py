@@ -140,9 +140,9 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    # conv launches are timed (HIP events attached to the dispatches) in a sample of the timed steps: every 8th one
-    # (all of them with --all-kernel-events) -- an event pair costs ~10 us of launch path, 250 conv launches per step
-    sampled = [i for i in range(args.steps) if args.all_kernel_events or i % 8 == 1 or args.steps < 2]
+    # conv launches are timed (HIP events attached to the dispatches) in ONE of the timed steps, the second
+    # (all of them with --all-kernel-events) -- an event pair costs ~10 us of launch path, 125 conv launches per step
+    sampled = [i for i in range(args.steps) if args.all_kernel_events or i == 1 or args.steps < 2]
     if timed_kernels:
         ops.conv_timer_begin(1 << 16)
         ops.conv_timer_arm(False)
