@@ -89,6 +89,16 @@ def cpu_baseline(w, cr, n_scans, seed=1):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started without the launcher: start it as a child (nothing has touched the GPU yet) and leave with its code
+        import socket
+        import subprocess
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     import torch
     import torch.distributed as dist
     from latte_amd import _lib, ops, synth
