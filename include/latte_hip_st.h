@@ -84,4 +84,10 @@ int lt_pseudo_label_fuse(const float* logits_2d, const float* logits_3d, const i
                          float* probs_3d, float* pc_2d, float* pc_3d, float* ps_conf, int32_t* ps_label,
                          lt_stream_t stream);
 
+/* torch.quantile(x, q) (linear interpolation) of a 1-D float array, result left on the device: out[0].  The thresholds
+ * of latte/tta/tools/latte.py:214-215.  One keys-only 32-bit radix sort instead of torch's (key, index) sort; rank and
+ * interpolation arithmetic as in ATen (fp32), so the result is torch's bit for bit on finite inputs.  No sync. */
+int64_t lt_quantile_workspace_bytes(int64_t n);
+int lt_quantile(const float* x, int64_t n, float q, void* ws, int64_t ws_bytes, float* out, lt_stream_t stream);
+
 #endif

@@ -87,6 +87,8 @@ SIGNATURES = {
     "lt_class_quantile_workspace_bytes": (I64, [I64]),
     "lt_class_quantile_mask": (ctypes.c_int, [P, P, I64, I32, F32, P, I64, P, P]),
     "lt_class_median_mask": (ctypes.c_int, [P, P, I64, I32, F32, P, I64, P, P]),
+    "lt_quantile_workspace_bytes": (I64, [I64]),
+    "lt_quantile": (ctypes.c_int, [P, I64, F32, P, I64, P, P]),
     "lt_pseudo_label_fuse": (ctypes.c_int, [P, P, P, P, P, P, P, I64, I64, I32, P, P, P, P, P, P]),
 }
 

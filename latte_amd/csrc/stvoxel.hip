@@ -567,3 +567,65 @@ extern "C" int lt_pseudo_label_fuse(const float* logits_2d, const float* logits_
   }
   return LT_OK;
 }
+
+
+// ---------------------------------------------------------------- torch.quantile(x, q) of a 1-D float array
+// (latte/tta/tools/latte.py:214-215: the conf_perc quantile of the ST-voxel entropies).  torch sorts (key, index) pairs;
+// here: order-preserving 32-bit keys, one keys-only radix sort, one thread picks the two order statistics and
+// interpolates with torch's own arithmetic (rank = q * (n - 1) in fp32, lerp as in ATen).  No sync: the result stays on the device.
+__global__ void k_q_keys(const float* __restrict__ x, int64_t n, unsigned* __restrict__ keys) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const unsigned b = __float_as_uint(x[i]);
+    keys[i] = (b & 0x80000000u) ? ~b : (b | 0x80000000u);  // ascending unsigned order = ascending float order
+  }
+}
+
+__device__ __forceinline__ float q_unkey(unsigned k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+
+__global__ void k_q_pick(const unsigned* __restrict__ skeys, int64_t n, float q, float* __restrict__ out) {
+#pragma clang fp contract(off)
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  const float rank = q * (float)(n - 1);
+  const float below = floorf(rank), above = ceilf(rank);
+  const float w = rank - below;
+  const float a = q_unkey(skeys[(int64_t)below]), b = q_unkey(skeys[(int64_t)above]);
+  // at::lerp: a + w (b - a) for w < 0.5, b - (b - a)(1 - w) otherwise
+  const float d = b - a;
+  *out = w < 0.5f ? a + w * d : b - d * (1.0f - w);
+}
+
+static int64_t q_sort_bytes(int64_t n) {
+  size_t b = 0;
+  unsigned* k = nullptr;
+  (void)rocprim::radix_sort_keys<LtSortConfig>(nullptr, b, k, k, (size_t)(n > 0 ? n : 1), 0, 32, (hipStream_t)0);
+  return (int64_t)b;
+}
+
+extern "C" int64_t lt_quantile_workspace_bytes(int64_t n) {
+  if (n < 1) n = 1;
+  return 2 * lt_align_up(n * 4, 256) + lt_align_up(q_sort_bytes(n), 256) + 1024;
+}
+
+extern "C" int lt_quantile(const float* x, int64_t n, float q, void* ws, int64_t ws_bytes, float* out,
+                           hipStream_t stream) {
+  LT_REQUIRE(n >= 1 && n < (1ll << 24), LT_ERR_RANGE, "lt_quantile: n=%lld must be in [1, 2^24) (ranks are fp32, as in torch)",
+             (long long)n);
+  LT_REQUIRE(q >= 0.f && q <= 1.f, LT_ERR_ARG, "lt_quantile: q must be in [0,1]");
+  LT_REQUIRE(x && ws && out, LT_ERR_ARG, "lt_quantile: null pointer");
+  LT_REQUIRE(ws_bytes >= lt_quantile_workspace_bytes(n), LT_ERR_WORKSPACE, "lt_quantile: workspace too small");
+  LtArena a(ws, ws_bytes);
+  unsigned* keys = (unsigned*)a.take(n * 4);
+  unsigned* skeys = (unsigned*)a.take(n * 4);
+  const int64_t sb = q_sort_bytes(n);
+  void* tmp = a.take(sb);
+  LT_REQUIRE(keys && skeys && tmp, LT_ERR_WORKSPACE, "lt_quantile: arena exhausted");
+  hipLaunchKernelGGL(k_q_keys, dim3(lt_grid(n, 256)), dim3(256), 0, stream, x, n, keys);
+  LT_LAUNCH_CHECK();
+  size_t sbs = (size_t)sb;
+  LT_CHECK_HIP(rocprim::radix_sort_keys<LtSortConfig>(tmp, sbs, keys, skeys, (size_t)n, 0, 32, stream));
+  hipLaunchKernelGGL(k_q_pick, dim3(1), dim3(64), 0, stream, skeys, n, q, out);
+  LT_LAUNCH_CHECK();
+  return LT_OK;
+}

@@ -524,6 +524,17 @@ def class_median_mask(vals, label, num_classes: int, cap: float):
     return keep.bool()
 
 
+def quantile(x: torch.Tensor, q: float) -> torch.Tensor:
+    """torch.quantile(x, q) of a 1-D float tensor as a 0-d device tensor (lt_quantile: no sync)."""
+    x = _chk(x.reshape(-1), torch.float32, "quantile x")
+    n = x.numel()
+    lib = _lib.load()
+    ws = _ws(lib.lt_quantile_workspace_bytes(n), x.device)
+    out = torch.empty(1, dtype=torch.float32, device=x.device)
+    _lib.call("lt_quantile", _p(x), n, float(q), _p(ws), ws.numel(), _p(out), _stream())
+    return out[0]
+
+
 def pseudo_label_fuse(logits_2d, logits_3d, fov_idx, st_ety_2d, st_ety_3d, thr_2d=None, thr_3d=None):
     """-> (pc_2d [Nf], pc_3d [N], ps_conf [N], ps_label int32 [N]); see lt_pseudo_label_fuse.  thr_*: 0-d device tensors."""
     l2 = _chk(logits_2d, torch.float32, "pl logits_2d")

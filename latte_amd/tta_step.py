@@ -349,8 +349,8 @@ class LatteStep:
             st3, st2 = hr23["hs_pc_ety"], hr32["hs_pc_ety"]
             thr2 = thr3 = None
             if self.conf_perc is not None and self.conf_perc >= 0:
-                thr3 = torch.quantile(st3, self.conf_perc)
-                thr2 = torch.quantile(st2, self.conf_perc)
+                thr3 = ops.quantile(st3, self.conf_perc)
+                thr2 = ops.quantile(st2, self.conf_perc)
             # softmax x2, point entropies, ST-entropy substitution, exp(-entropy) blend inside the FOV, max: 2 kernels
             pc2, pc3, ps_conf, ps_label = ops.pseudo_label_fuse(ema_logit_2d, ema3d["seg_logit"], fov_idx, st2, st3,
                                                                 thr2, thr3)

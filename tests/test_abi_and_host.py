@@ -41,6 +41,7 @@ def test_size_queries_need_no_gpu():
     assert lib.lt_spconv_packed_floats(27, 96, 96) == 27 * 96 * 96
     for fn in ("lt_unique_workspace_bytes", "lt_downsample_workspace_bytes", "lt_kmap_workspace_bytes",
                "lt_sort_segments_workspace_bytes", "lt_class_quantile_workspace_bytes", "lt_kmap_order_workspace_bytes",
+               "lt_quantile_workspace_bytes",
                "lt_kmap_plan_workspace_bytes"):
         assert getattr(lib, fn)(100000) > 0
 

@@ -168,3 +168,27 @@ def test_pseudo_label_fuse_edge_cases():
     with pytest.raises(RuntimeError):
         ops.pseudo_label_fuse(torch.zeros(0, 65, device=dev), torch.zeros(4, 65, device=dev),
                               torch.zeros(0, dtype=torch.int64, device=dev), e, torch.zeros(4, device=dev))
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 1000, 208896])
+@pytest.mark.parametrize("q", [0.0, 0.5, 0.9, 1.0])
+def test_quantile_matches_torch(n, q):
+    """lt_quantile (keys-only radix sort + one interpolation) against torch.quantile: same value (ATen's fp32 rank and
+    lerp arithmetic are reproduced), with negative values, zeros and ties in the input."""
+    from latte_amd import ops
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(n, generator=g)
+    x[torch.rand(n, generator=g) < 0.3] = 0.0                     # many points have no ST voxel: entropy 0
+    x = x.cuda()
+    got = ops.quantile(x, q)
+    want = torch.quantile(x, q)
+    assert got.shape == want.shape == torch.Size([])
+    assert torch.allclose(got, want, rtol=1e-6, atol=1e-7), (float(got), float(want))
+
+
+def test_quantile_rejects_bad_arguments():
+    from latte_amd import ops
+    with pytest.raises(RuntimeError):
+        ops.quantile(torch.zeros(0, device="cuda"), 0.5)
+    with pytest.raises(RuntimeError):
+        ops.quantile(torch.zeros(8, device="cuda"), 1.5)
