@@ -130,7 +130,14 @@ def make_case(name, n, B, C, W, vs, R, beams, full_360, seq_len, seed):
           "loss23", out["23_cr_loss"], "loss32", out["32_cr_loss"])
 
 
+CASES = {
+    "tiny": dict(n=2048, B=3, C=5, W=3, vs=0.4, R=30, beams=16, full_360=False, seq_len=3, seed=0),
+    "twoseq": dict(n=4096, B=6, C=9, W=3, vs=0.2, R=40, beams=32, full_360=False, seq_len=3, seed=1),
+    "w5_360": dict(n=3072, B=5, C=16, W=5, vs=0.2, R=50, beams=32, full_360=True, seq_len=5, seed=2),
+    # BASELINE configs[2] (A2D2 -> SemanticKITTI: latte/config/xmuda.py:293-298 knobs vs 0.1, R 40, W 3; 10 classes, B 6)
+    "a2d2": dict(n=4096, B=6, C=10, W=3, vs=0.1, R=40, beams=64, full_360=False, seq_len=6, seed=3),
+}
+
 if __name__ == "__main__":
-    make_case("tiny", n=2048, B=3, C=5, W=3, vs=0.4, R=30, beams=16, full_360=False, seq_len=3, seed=0)
-    make_case("twoseq", n=4096, B=6, C=9, W=3, vs=0.2, R=40, beams=32, full_360=False, seq_len=3, seed=1)
-    make_case("w5_360", n=3072, B=5, C=16, W=5, vs=0.2, R=50, beams=32, full_360=True, seq_len=5, seed=2)
+    for name in (sys.argv[1:] or list(CASES)):   # no argument: every case; otherwise the named ones
+        make_case(name, **CASES[name])
