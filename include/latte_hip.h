@@ -156,6 +156,13 @@ int lt_conv_debug_stamps(void* buf, int64_t cap_words);
 int64_t lt_bn_workspace_bytes(int64_t V, int32_t C);
 int lt_bn_stats(const float* x, int64_t V, int32_t C, void* ws, int64_t ws_bytes, float* mean, float* var,
                 lt_stream_t stream);
+/* lt_bn_stats for callers that cannot allocate (HIP graph capture, serving loops, harnesses that forbid hipMalloc): NO
+ * counterpart in the reference.  Same kernels and results as lt_bn_stats, but the per-block partial sums live in a
+ * file-scope device array of the library (2 MiB per GPU, held until the process ends) instead of a caller workspace;
+ * the call allocates nothing.  Limit: C <= 256 (LT_ERR_RANGE beyond it).  The first call on a device looks the array's
+ * address up (with that device current, which must be the stream's device).  All calls on one GPU share the array:
+ * calls that overlap on one GPU (different streams) race -- serialise them. */
+int lt_bn_stats_static(const float* x, int64_t V, int32_t C, float* mean, float* var, lt_stream_t stream);
 /* mean / biased variance from the column sums lt_spconv_plan_fwd_stats left in stats_ws (V = Vout, C = Cout of that call) */
 int lt_bn_finalize_sums(void* stats_ws, int64_t V, int32_t C, float* mean, float* var, lt_stream_t stream);
 /* relu: 0 = y = bn(x) + residual;  1 = y = relu(bn(x) + residual)  (ResidualBlock, basic_blocks.py:72-75);

@@ -61,6 +61,7 @@ SIGNATURES = {
     "lt_spconv_fwd": (ctypes.c_int, [P, P, P, P, P, I64, I64, I32, I32, I32, P]),
     "lt_bn_workspace_bytes": (I64, [I64, I32]),
     "lt_bn_stats": (ctypes.c_int, [P, I64, I32, P, I64, P, P, P]),
+    "lt_bn_stats_static": (ctypes.c_int, [P, I64, I32, P, P, P]),
     "lt_bn_apply": (ctypes.c_int, [P, P, P, P, P, F32, P, I32, P, I64, I32, P]),
     "lt_bn_bwd_reduce": (ctypes.c_int, [P, P, P, P, P, P, P, F32, I32, I64, I32, P, I64, P, P, P]),
     "lt_bn_bwd_apply": (ctypes.c_int, [P, P, P, P, P, P, P, F32, I32, P, P, P, P, I64, I32, P]),

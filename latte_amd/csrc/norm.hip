@@ -8,6 +8,7 @@
 // loads, a wave reads whole rows), partial sums per block go to a workspace, the finalising kernel combines
 // them in fp64.  Sums are shifted by row 0 so that var = E[d^2]-E[d]^2 does not cancel when |mean| >> std.
 #include "common.h"
+#include <mutex>
 #include "../../include/latte_hip.h"
 
 #define BN_BLOCK 256
@@ -253,6 +254,51 @@ extern "C" int lt_bn_stats(const float* x, int64_t V, int32_t C, void* ws, int64
   StatsOp op{x};
   hipLaunchKernelGGL(k_col_partial<StatsOp>, dim3(nb), dim3(BN_BLOCK), (size_t)rpi * 2 * C * 4, stream, op, V, C,
                      (float*)ws);
+  LT_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_bn_finalize, dim3(C), dim3(64), 0, stream, (const float*)ws, nb, x, V, C, mean, var);
+  LT_LAUNCH_CHECK();
+  return LT_OK;
+}
+
+// ---- the entry point that allocates nothing (task item 7): lt_bn_stats with the per-block partial sums in a file-scope
+// device array instead of a caller workspace.  Each GPU holds its own copy of the array at its own address: the address
+// is looked up once per device (hipGetSymbolAddress with that device current) and only that pointer is ever handed to a
+// kernel.  Every partial the finalising kernel reads is written by the launch before it, so nothing needs clearing.
+#define LT_BN_STATIC_MAX_C 256
+#define LT_BN_STATIC_MAX_DEVICES 64
+static __device__ __align__(256) float scratch[(size_t)BN_MAX_BLOCKS * 2 * LT_BN_STATIC_MAX_C];
+static float* g_scratch_ptr[LT_BN_STATIC_MAX_DEVICES];
+static std::mutex g_scratch_mu;
+
+static int bn_static_scratch(float** out) {
+  int dev = -1;
+  LT_CHECK_HIP(hipGetDevice(&dev));
+  LT_REQUIRE(dev >= 0 && dev < LT_BN_STATIC_MAX_DEVICES, LT_ERR_RANGE, "lt_bn_stats_static: device %d out of range", dev);
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  if (!g_scratch_ptr[dev]) {
+    void* p = nullptr;
+    LT_CHECK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    LT_REQUIRE(p != nullptr, LT_ERR_HIP, "lt_bn_stats_static: no device address for the scratch array on device %d", dev);
+    g_scratch_ptr[dev] = (float*)p;
+  }
+  *out = g_scratch_ptr[dev];
+  return LT_OK;
+}
+
+extern "C" int lt_bn_stats_static(const float* x, int64_t V, int32_t C, float* mean, float* var, hipStream_t stream) {
+  int rc = check_vc("lt_bn_stats_static", V, C);
+  if (rc) return rc;
+  LT_REQUIRE(C <= LT_BN_STATIC_MAX_C, LT_ERR_RANGE,
+             "lt_bn_stats_static: C=%d exceeds the built-in scratch (max %d channels); use lt_bn_stats with a workspace", C,
+             LT_BN_STATIC_MAX_C);
+  LT_REQUIRE(x && mean && var, LT_ERR_ARG, "lt_bn_stats_static: null pointer");
+  float* ws = nullptr;
+  rc = bn_static_scratch(&ws);
+  if (rc) return rc;
+  const int nb = bn_blocks(V, C);
+  const int cg = C / 4, rpi = BN_BLOCK / cg > 0 ? BN_BLOCK / cg : 1;
+  StatsOp op{x};
+  hipLaunchKernelGGL(k_col_partial<StatsOp>, dim3(nb), dim3(BN_BLOCK), (size_t)rpi * 2 * C * 4, stream, op, V, C, ws);
   LT_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_bn_finalize, dim3(C), dim3(64), 0, stream, (const float*)ws, nb, x, V, C, mean, var);
   LT_LAUNCH_CHECK();
