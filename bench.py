@@ -5,16 +5,27 @@
 
 A step = teacher SPVCNN forward + student SPVCNN forward + 2x HR_Block (ST-voxel aggregation) + pseudo-label fusion +
 2x CR_Block + cross-entropy + backward to the BatchNorm parameters + (N>1: one flat RCCL all-reduce of those grads) +
-Adam + EMA teacher update -- latte/tta/tools/latte.py:156-323 without the 2-D SegFormer.
-Workload at every N: BASELINE.json configs[1] (nuScenes-like 34 816-point 360-degree scans, 5-frame ST window, 6 scans
-per step and GPU, 16 classes, SPVCNN cr=1.0, fp32); every rank owns its own sequence (weak scaling, no data-path
-collective).  Inputs are resident in HBM before the timed region.
+Adam + EMA teacher update -- latte/tta/tools/latte.py:156-323 without the 2-D SegFormer.  Inputs are
+resident in HBM before the timed region; index structures are rebuilt from the coordinates in every step.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline      the dominant kernel family (sparse-conv fp32 MFMA kernel k_spconv_sj): algorithmic flops / HIP-event time of its
-                launches of a sample of the timed steps (the library's conv launch timer, lt_conv_timer_begin/end)
+Workloads (latte_amd/synth.py restates BASELINE.json's configs):
+  N = 1   a2d2_kitti_128k  BASELINE configs[2], the largest single-GPU config: 6 x 131 072-point scans, 5 cm input voxels,
+          ST voxels 0.1 m / R 40 m / 3-frame window, 10 classes, SPVCNN cr = 1.0, fp32.  configs[0] / configs[1]
+          (synthia_kitti_32k, nuscenes_34k_w5) are measured right after it and reported in `other_workloads`.
+  N > 1   multiseq_64      BASELINE configs[3]: 64 scans per step = 8 sequences x 8 frames of 34 816 points, sequences
+          dealt to the ranks (4/2/1 per GPU at N = 2/4/8), STRONG scaling: total work fixed, no data-path collective, one
+          flat all-reduce of the 13 248 BatchNorm grads.  Its one-GPU base: `--gpus 1 --workload multiseq_64`.
+  --workload conv_1m       BASELINE configs[4]: 3^3 conv over >= 1 M voxels, C = 16..256, plus one U-Net forward over them.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
+  roofline      the dominant kernel family (fp32-MFMA sparse conv): algorithmic flops / HIP-event time of its launches in a
+                sampled timed step (the library's conv launch timer: events on the stream the kernel is launched on);
+                `hbm_classes`: achieved GB/s of the HBM-bound kernel classes (hash/unique, kernel-map query, voxelize,
+                devoxelize, BatchNorm, segmented reduction, join): algorithmic bytes of SURVEY 8d / HIP-event time, each
+                kernel run on the tensors of this workload
   cpu_baseline  the CPU oracle (oracle/step_ref.py, a port: the reference's torchsparse backend is not installable)
-                timed on this box's host cores on a bounded sample of the same workload
+                timed on this box's host cores on a bounded sample of the same workload, with OMP_NUM_THREADS = 4 (the
+                value the reference pins, latte/tta/tools/latte.py:7) and with all cores the box gives
 """
 from __future__ import annotations
 
@@ -29,7 +40,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense, spec
-PEAK_HBM_GBS = 8000.0
+PEAK_HBM_GBS = 8000.0         # same guide: HBM3E 8 TB/s spec
+METRIC = "points/sec per sparse-conv 3D fwd+ST-voxel TTA step"
 
 
 def parse():
@@ -37,10 +49,13 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="nuscenes_34k_w5")
+    ap.add_argument("--workload", default=None, help="default: a2d2_kitti_128k at --gpus 1, multiseq_64 (sequences "
+                    "sharded, strong scaling) at --gpus N > 1; conv_1m = the sparse-conv micro-benchmark")
     ap.add_argument("--cr", type=float, default=1.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-scans", type=int, default=3, help="scans in the CPU-oracle sample")
+    ap.add_argument("--cpu-scans", type=int, default=None, help="scans in the CPU-oracle sample (default: sized to ~20 s)")
+    ap.add_argument("--no-other-workloads", action="store_true", help="skip the configs[0]/[1] lines of other_workloads")
+    ap.add_argument("--no-hbm-classes", action="store_true", help="skip the per-class HBM GB/s measurements")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not time the conv launches with HIP events")
     ap.add_argument("--all-kernel-events", action="store_true", help="time the conv launches of every timed step")
     ap.add_argument("--no-side-stream", action="store_true", help="run the input-only, sync-heavy work (index structures, "
@@ -48,19 +63,21 @@ def parse():
     ap.add_argument("--no-prefetch", action="store_true", help="build the index structures of a batch inside its own step "
                     "instead of one step ahead")
     ap.add_argument("--dump-conv", default=None, help="write the per-launch conv table of one step (JSON) here")
-    ap.add_argument("--fwd-only", action="store_true", help="time teacher forward only (BASELINE config 5 style)")
+    ap.add_argument("--fwd-only", action="store_true", help="time teacher forward only")
     return ap.parse_args()
 
 
-def cpu_baseline(w, cr, n_scans, seed=1):
-    """Oracle TTA step (teacher fwd, student fwd, 2x HR, 2x CR, CE, backward) on `n_scans` scans of the workload."""
-    import numpy as np
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def _cpu_leg(w, cr, n_scans, threads, seed=1):
+    """Oracle TTA step (quantize, teacher fwd, student fwd, 2x HR, 2x CR, CE, backward) on `n_scans` scans of the workload
+    with `threads` torch-CPU threads."""
     import torch
     from latte_amd import synth
     from latte_amd.spvcnn import Net3DSeg
     from latte_amd.workload import hr_cfg_of
     from oracle import step_ref
 
+    torch.set_num_threads(int(threads))
     torch.manual_seed(seed)
     model = Net3DSeg(w["C"], True, "SPVCNN", {"cr": cr})
     sd = model.state_dict()
@@ -73,18 +90,285 @@ def cpu_baseline(w, cr, n_scans, seed=1):
     g = torch.Generator().manual_seed(0)
     l2s = 3 * torch.randn(n_fov, w["C"], generator=g)
     l2t = 3 * torch.randn(n_fov, w["C"], generator=g)
-    cores = torch.get_num_threads()
     t0 = time.perf_counter()
     coords, feats, invs, sizes = step_ref.quantize_batch(scans)
     step_ref.tta_step_ref(sd, sd, coords, torch.from_numpy(feats), invs, sizes, ori, fov,
                           [synth.make_pose(j) for j in range(n_scans)], ["scene-1000"] * n_scans, list(range(n_scans)),
                           l2s, l2t, hr_cfg_of(w), grad_names=names)
     dt = time.perf_counter() - t0
-    pts = n_scans * w["n"]
-    return {"value": pts / dt, "unit": "points/s", "cores": int(cores), "kind": "port",
-            "sample": f"one oracle TTA step (oracle/step_ref.py: quantize, teacher fwd, student fwd, 2x HR, 2x CR, CE, "
-                      f"backward) on {n_scans} scans x {w['n']} points of the same workload, {dt:.1f} s, torch-CPU "
-                      f"fp32 with {cores} threads; the reference's own backend (torchsparse v1.4.0 CUDA) cannot run here"}
+    return {"value": n_scans * w["n"] / dt, "unit": "points/s", "cores": int(threads), "seconds": round(dt, 2),
+            "scans": n_scans, "points": n_scans * w["n"]}
+
+
+def cpu_baseline(w, cr, n_scans=None):
+    """Two legs on the same bounded sample: all cores the box gives this process, and the reference's OMP_NUM_THREADS=4."""
+    import torch
+    all_cores = int(torch.get_num_threads())
+    if n_scans is None:
+        # ~20 s of CPU work in total over the two legs: the oracle runs ~12-15 k points/s on 16 threads
+        n_scans = max(1, min(w["B"], int(round(110_000 / w["n"]))))
+    full = _cpu_leg(w, cr, n_scans, all_cores)
+    omp4 = _cpu_leg(w, cr, n_scans, min(4, all_cores))
+    torch.set_num_threads(all_cores)
+    sample = (f"one oracle TTA step (oracle/step_ref.py: quantize, teacher fwd, student fwd, 2x HR, 2x CR, CE, backward) on "
+              f"{n_scans} scan(s) x {w['n']} points of the same workload (the step's batch is {w['B']} scans), torch-CPU "
+              f"fp32: {full['seconds']} s with {all_cores} threads, {omp4['seconds']} s with {omp4['cores']} threads "
+              f"(the reference pins OMP_NUM_THREADS=4); the reference's own backend (torchsparse v1.4.0 CUDA) cannot run here")
+    return {"value": full["value"], "unit": "points/s", "cores": all_cores, "kind": "port", "sample": sample,
+            "omp4": {"value": omp4["value"], "unit": "points/s", "cores": omp4["cores"], "seconds": omp4["seconds"]},
+            "seconds": full["seconds"]}
+
+
+# ------------------------------------------------------------------------------------------------ HBM-bound kernel classes
+def _event_us(fn, reps=10, rounds=3):
+    """best-of-`rounds` average GPU time of fn() in us, HIP events on torch's current stream = the stream every lt_* kernel
+    is launched on (ops._stream)."""
+    import torch
+    fn()
+    fn()
+    best = float("inf")
+    for _ in range(rounds):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, 1e3 * e0.elapsed_time(e1) / reps)
+    return best
+
+
+def hbm_classes(batch, w, hr):
+    """Achieved HBM GB/s per kernel class: ALGORITHMIC bytes (SURVEY 8d formulas, restated in DESIGN.md 4) / HIP-event time
+    of the library call on this workload's own tensors.  N = points the backbone sees (unique input voxels), V = voxels
+    of x0 (= N: the input is already unique), M = pairs of the stride-1 3^3 map."""
+    import torch
+    from latte_amd import functional as LF
+    from latte_amd import ops
+    from latte_amd import sparse_modules as spnn
+    from latte_amd.point_voxel import initial_voxelize, v2p_index
+    from latte_amd.tensor import PointTensor
+
+    lidar = batch["lidar"]
+    dev = lidar.C.device
+    z = PointTensor(lidar.F, lidar.C.float())
+    x0 = initial_voxelize(z, 0.05, 0.05)
+    N, V = int(lidar.C.shape[0]), int(x0.C.shape[0])
+    out = {}
+
+    def add(name, us, nbytes, what):
+        out[name] = {"us": round(us, 1), "bytes": int(nbytes), "GBs": round(nbytes / us / 1e3, 1),
+                     "frac_hbm": round(nbytes / us / 1e3 / PEAK_HBM_GBS, 4), "what": what}
+
+    # hash + unique (initial_voxelize: FNV hash of every point, sorted unique hashes, point -> voxel inverse)
+    ci = lidar.C.int().contiguous()
+
+    def hash_unique():
+        h = ops.sphash(ci)
+        ops.unique_sorted(h, key_bits=60, want_first=False)
+    add("hash_unique", _event_us(hash_unique), 16 * N + 8 * N + 20 * V,
+        "lt_sphash + lt_unique_sorted over the batch's points: 16N + 8N + 20V")
+    # kernel-map query, 3^3 at stride 1
+    off = LF.get_kernel_offsets(3, 1, 1, device=dev)
+    res = ops.kmap_build(x0.C, x0.C, off)
+    M = int((res >= 0).sum())
+    add("kmap_query", _event_us(lambda: ops.kmap_build(x0.C, x0.C, off)), 16 * V + 16 * V + 8 * M,
+        "lt_kmap_build 3^3 stride 1 (table insert + 27 probes per voxel): 16Vin + 16Vout + 8M")
+    # voxelize (scatter-mean point -> voxel as an atomic-free CSR gather), C = 32
+    idx = z.additional_features["idx_query"][1]
+    csr = z.additional_features["p2v_csr"][x0.s]
+    f32 = torch.randn(N, 32, device=dev)
+    add("voxelize", _event_us(lambda: ops.voxelize_csr_fwd(f32, csr, V)), 4 * N * 32 + 4 * N + 4 * V * 32,
+        "lt_voxelize_csr_fwd C=32 (scatter-mean as sorted segments): 4NC + 4N + 4VC")
+    # devoxelize (8-corner trilinear gather), C = 96
+    iq, wt = v2p_index(x0, z)
+    f96 = torch.randn(V, 96, device=dev)
+    add("devoxelize", _event_us(lambda: ops.devoxelize_fwd(f96, iq, wt)), 64 * N + 4 * V * 96 + 4 * N * 96,
+        "lt_devoxelize_fwd C=96 (8 gathered rows per point): 64N + 4VC + 4NC")
+    # BatchNorm: statistics, apply(+ReLU), backward (reduce + apply) at [V, 96]
+    gamma, beta = torch.ones(96, device=dev), torch.zeros(96, device=dev)
+    mean, var = ops.bn_stats(f96)
+    add("bn_stats", _event_us(lambda: ops.bn_stats(f96)), 4 * V * 96, "lt_bn_stats [V,96]: 4VC")
+    y = torch.empty_like(f96)
+    add("bn_apply_relu", _event_us(lambda: ops.bn_apply(f96, mean, var, gamma, beta, 1e-5, relu=True, out=y)), 8 * V * 96,
+        "lt_bn_apply [V,96] with ReLU: 8VC")
+    dy = torch.randn(V, 96, device=dev)
+    add("bn_backward", _event_us(lambda: ops.bn_bwd(dy, f96, None, mean, var, gamma, 1e-5, True, beta=beta)), 24 * V * 96,
+        "lt_bn_bwd_reduce + lt_bn_bwd_apply [V,96], ReLU mask rebuilt from x: 24VC")
+    # ST-voxel stage: segmented mean over sorted voxel keys, softmax+entropy, sorted-set join
+    extra = {k: batch[k] for k in ("pose", "scene_name", "scan_ID", "img_indices", "ori_points")}
+    geo = hr.geometry(extra, "3D", extra, "3D")
+    C = w["C"]
+    P = geo["Ph"]
+    logits = 3 * torch.randn(P, C, device=dev)
+    add("softmax_entropy", _event_us(lambda: ops.softmax_entropy(logits)), 4 * P * C * 2 + 4 * P,
+        "lt_softmax_entropy [P,C_cls]: 8PC + 4P")
+    probs, _ = ops.softmax_entropy(logits)
+    E, Vt = int(geo["h_selem"].numel()), int(geo["h_seg"].numel()) - 1
+    add("segment_reduce", _event_us(lambda: ops.segment_reduce(probs, geo["h_selem"], geo["h_seg"], "mean", src_index=geo["h_src"])),
+        4 * E * C + 8 * E + 4 * Vt * C + 4 * Vt,
+        "lt_segment_reduce mean of hist probabilities over ST voxels: 4E*C (gathered rows) + 8E (two indices) + 4Vt*C + 4Vt")
+    a_keys, h_keys = None, None
+    # the join's inputs are the sorted unique keys of both sides: rebuild them the way geometry() does
+    pts = torch.cat([p.reshape(-1, 3) for p in batch["ori_points"]], 0).float()
+    sizes = [int(p.shape[0]) for p in batch["ori_points"]]
+    import numpy as np
+    st = torch.as_tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int64, device=dev)
+    anc = torch.arange(len(sizes), dtype=torch.int32, device=dev)
+    keys, _ = ops.st_keys(pts, st, st[:-1].contiguous(), anc, None, int(pts.shape[0]), hr.max_range, hr.voxel_size, hr.min_offset)
+    _, _, a_uk, _ = ops.sort_segments(keys)
+    add("sort_segments", _event_us(lambda: ops.sort_segments(keys)), 8 * P + 8 * P + 12 * int(a_uk.numel()),
+        "lt_sort_segments of the anchor keys (radix sort + segment heads): 8P keys + 8P (sorted elem, inverse) + 12V")
+    add("st_join", _event_us(lambda: ops.st_join(a_uk, a_uk)), 8 * 2 * int(a_uk.numel()),
+        "lt_st_join of two sorted voxel-key sets: 8(Va + Vt)")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ conv micro-benchmark
+def run_conv_1m(args):
+    """BASELINE configs[4]."""
+    import torch
+    from latte_amd import _lib, ops
+    from latte_amd import sparse_modules as spnn
+    from latte_amd.spvcnn import SPVCNN
+    from latte_amd.tensor import SparseTensor
+    from latte_amd.workload import build_conv_1m
+    _lib.load()
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    x0 = build_conv_1m(device=dev)
+    kmap, _ = spnn.build_kernel_map(x0, 3, 1, 1)
+    res, plan = kmap.results, kmap.plan()
+    V = int(res.shape[1])
+    M = int((res >= 0).sum())
+    rows = []
+    for C in (16, 32, 64, 96, 128, 256):
+        feats = torch.randn(V, C, device=dev)
+        pw = ops.pack_weights(torch.randn(27, C, C, device=dev) * 0.05, 0)
+        us = _event_us(lambda: ops.spconv_plan(feats, pw, plan, 27, V, C), reps=max(args.steps, 5))
+        flops = 2.0 * M * C * C
+        comp = 4.0 * (2 * V * C + 27 * C * C) + 8.0 * M
+        intensity = flops / comp
+        bound = "mfma" if intensity > PEAK_F32_MFMA_TFLOPS * 1e3 / PEAK_HBM_GBS else "hbm"
+        rows.append({"C": C, "us": round(us, 1), "tflops": round(flops / us / 1e6, 2),
+                     "frac_mfma": round(flops / us / 1e6 / PEAK_F32_MFMA_TFLOPS, 4),
+                     "compulsory_GBs": round(comp / us / 1e3, 1), "frac_hbm": round(comp / us / 1e3 / PEAK_HBM_GBS, 4),
+                     "flop_per_byte": round(intensity, 1), "bound": bound})
+    # one U-Net forward over the same voxels (features: 4 random channels, like the network's input)
+    torch.manual_seed(1)
+    net = SPVCNN(cr=args.cr).to(dev).train()
+    lidar = SparseTensor(torch.randn(V, 4, device=dev), x0.C, 1)
+
+    def fwd():
+        lidar._lt_cache = None
+        with torch.no_grad():
+            net(lidar)
+    for _ in range(max(args.warmup, 1)):
+        fwd()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        fwd()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    best = max(rows, key=lambda r: r["frac_mfma"])
+    out = {"metric": "voxels/sec, SPVCNN 3D U-Net forward over 1M voxels (BASELINE configs[4])", "value": V / dt,
+           "unit": "voxels/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "conv_1m", "voxels": V, "pairs_3x3x3": M, "pairs_per_voxel": round(M / V, 2),
+                      "spvcnn_cr": args.cr},
+           "roofline": {"bound": "mfma", "achieved": best["tflops"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": best["frac_mfma"], "traffic": None,
+                        "kernel": f"k_spconv_sj, 3^3 conv Cin = Cout = {best['C']} over {V} voxels (best of the table)"},
+           "conv_table": rows, "cpu_baseline": None}
+    print(json.dumps(out), flush=True)
+
+
+# ------------------------------------------------------------------------------------------------ the step benchmark
+def time_steps(step, batch, args, world, dev, backend, fwd_only=False, steps=None, warmup=None, kernel_events=True):
+    """-> dict(dt, dt_host, trace, sampled, pairs).  W untimed warm-up steps, then exactly K steps between
+    barrier + synchronize on both sides, max over ranks."""
+    import torch
+    import torch.distributed as dist
+    from latte_amd import ops
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
+
+    def one_step():
+        if fwd_only:
+            with torch.no_grad():
+                return step.ema_model(batch)
+        # the synthetic workload feeds the same scans every step: `next_batch=batch` makes the step issue the NEXT
+        # iteration's input-only structures (rebuilt from the coordinates, not reused) while its own backward runs
+        return step.step(batch, next_batch=None if args.no_prefetch else batch)
+
+    for _ in range(warmup):
+        one_step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    # conv launches are timed (HIP events attached to the dispatches) in ONE of the timed steps, the second
+    # (all of them with --all-kernel-events) -- an event pair costs ~10 us of launch path, 125 conv launches per step
+    sampled = [i for i in range(steps) if args.all_kernel_events or i == 1 or steps < 2]
+    if kernel_events:
+        ops.conv_timer_begin(1 << 16)
+        ops.conv_timer_arm(False)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        if kernel_events and i in sampled:
+            ops.conv_timer_arm(True)
+            one_step()
+            ops.conv_timer_arm(False)
+        else:
+            one_step()
+    dt_host = time.perf_counter() - t0  # the host has issued every step (the GPU may still be working)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    trace = ops.conv_timer_end() if kernel_events else None
+    t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    pairs = None
+    if kernel_events:
+        # pair counts M of every conv launch of a step, from one more (untimed) step on every rank: the launch sequence
+        # and the kernel maps are the same in every step (same scans), only the BN parameters move
+        ops.CONV_PAIRS = []
+        one_step()
+        torch.cuda.synchronize()
+        pairs = [int(m.item()) for m in ops.CONV_PAIRS]
+        ops.CONV_PAIRS = None
+    step.close()
+    return dict(dt=dt, dt_host=dt_host, trace=trace, sampled=sampled, pairs=pairs, steps=steps)
+
+
+def conv_roofline(r, args):
+    ms, meta = r["trace"]
+    sampled, pairs = r["sampled"], r["pairs"]
+    n_s = len(sampled)
+    per_step = len(ms) // n_s
+    assert len(pairs) == per_step and per_step * n_s == len(ms), (len(pairs), per_step, len(ms))
+    flops_step = sum(2.0 * m * int(cin) * int(cout) for m, (cin, cout, _k, _v) in zip(pairs, meta[:per_step]))
+    ms_total = float(ms.astype("float64").sum())
+    if args.dump_conv:
+        us = 1e3 * ms.reshape(n_s, per_step).mean(0)
+        table = [dict(i=i, Cin=int(c[0]), Cout=int(c[1]), K=int(c[2]), Vout=int(c[3]), M=m, us=round(float(u), 1),
+                      tflops=round(2.0 * m * int(c[0]) * int(c[1]) / float(u) / 1e6, 2))
+                 for i, (m, c, u) in enumerate(zip(pairs, meta[:per_step], us))]
+        json.dump(table, open(args.dump_conv, "w"))
+    launches = len(ms)
+    flops_total = flops_step * n_s
+    achieved = flops_total / (ms_total * 1e-3) / 1e12
+    return {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "kernel": "sparse-conv family (k_spconv_sj<SR,NTW,W> split-j fp32 MFMA; 4-channel stem: k_spconv_scalar): every "
+                      "conv launch of the sampled steps of the timed region",
+            "launches": launches, "avg_launch_us": round(1e3 * ms_total / launches, 2),
+            "flops_per_launch": round(flops_total / launches),
+            "timed_steps": sampled,
+            "share_of_step": round(ms_total * 1e-3 / n_s / (r["dt"] / r["steps"]), 4)}
 
 
 def main():
@@ -101,9 +385,9 @@ def main():
         raise SystemExit(subprocess.call(cmd))
     import torch
     import torch.distributed as dist
-    from latte_amd import _lib, ops, synth
+    from latte_amd import _lib, synth
     from latte_amd.spvcnn import Net3DSeg
-    from latte_amd.tta_step import LatteStep, shard_scan_offset
+    from latte_amd.tta_step import LatteStep, shard_scan_offset, shard_sequences
     from latte_amd.workload import build_batch, hr_cfg_of
 
     if os.environ.get("LATTE_BENCH_TRACE"):  # where a stuck multi-rank run stands: Python stacks of every rank after 60 s
@@ -114,6 +398,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    if args.workload == "conv_1m":
+        if world > 1:
+            raise SystemExit("--workload conv_1m is a one-GPU micro-benchmark")
+        return run_conv_1m(args)
     _lib.load()
     # LATTE_BENCH_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks (ranks share GPUs)
     backend = os.environ.get("LATTE_BENCH_BACKEND", "nccl")
@@ -129,108 +417,84 @@ def main():
             dist.init_process_group(backend)
         pg = dist.group.WORLD
 
-    w = synth.workload(args.workload)
+    name = args.workload or ("a2d2_kitti_128k" if world == 1 else "multiseq_64")
+    w = synth.workload(name)
+    scaling = "weak"
+    total_scans = w["B"] * world
+    if name == "multiseq_64":
+        # BASELINE configs[3]: the 64 scans of ONE step are dealt to the ranks by whole sequences (strong scaling)
+        n_seq = w["B"] // w["seq_len"]
+        if world > n_seq:
+            raise SystemExit(f"multiseq_64 has {n_seq} sequences: at most {n_seq} ranks")
+        s0, ns = shard_sequences(n_seq, world, rank)
+        total_scans = w["B"]
+        w_rank = dict(w, B=ns * w["seq_len"])
+        scan_offset = s0 * w["seq_len"]
+        scaling = "strong"
+    else:
+        w_rank = w
+        scan_offset = shard_scan_offset(rank, w["B"])     # weak scaling: every rank owns its own B scans
     torch.manual_seed(1)  # cfg.RNG_SEED (latte/common/config/base.py:173); same weights on every rank
     model = Net3DSeg(w["C"], True, "SPVCNN", {"cr": args.cr}).to(dev)
     step = LatteStep(model, w["C"], hr_cfg_of(w), process_group=pg, side_stream=not args.no_side_stream)
-    batch = build_batch(w, device=dev, scan_offset=shard_scan_offset(rank, w["B"]), seed=rank)
-    n_points = batch["n_points"]
+    batch = build_batch(w_rank, device=dev, scan_offset=scan_offset, seed=rank)
+    n_points_total = total_scans * w["n"]
 
-    def one_step():
-        if args.fwd_only:
-            with torch.no_grad():
-                return step.ema_model(batch)
-        # the synthetic workload feeds the same scans every step: `next_batch=batch` makes the step issue the NEXT
-        # iteration's input-only structures (rebuilt from the coordinates, not reused) while its own backward runs
-        return step.step(batch, next_batch=None if args.no_prefetch else batch)
+    r = time_steps(step, batch, args, world, dev, backend, fwd_only=args.fwd_only, kernel_events=not args.no_kernel_events)
+    dt = r["dt"]
 
-    for _ in range(args.warmup):
-        one_step()
-    timed_kernels = not args.no_kernel_events
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    # conv launches are timed (HIP events attached to the dispatches) in ONE of the timed steps, the second
-    # (all of them with --all-kernel-events) -- an event pair costs ~10 us of launch path, 125 conv launches per step
-    sampled = [i for i in range(args.steps) if args.all_kernel_events or i == 1 or args.steps < 2]
-    if timed_kernels:
-        ops.conv_timer_begin(1 << 16)
-        ops.conv_timer_arm(False)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        if timed_kernels and i in sampled:
-            ops.conv_timer_arm(True)
-            one_step()
-            ops.conv_timer_arm(False)
-        else:
-            one_step()
-    dt_host = time.perf_counter() - t0  # the host has issued every step (the GPU may still be working)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    trace = ops.conv_timer_end() if timed_kernels else None
-    t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
-    pairs = None
-    if timed_kernels:
-        # pair counts M of every conv launch of a step, from one more (untimed) step on every rank: the launch sequence
-        # and the kernel maps are the same in every step (same scans), only the BN parameters move
-        ops.CONV_PAIRS = []
-        one_step()
-        torch.cuda.synchronize()
-        pairs = [int(m.item()) for m in ops.CONV_PAIRS]
-        ops.CONV_PAIRS = None
-
-    step.close()
     if rank == 0:
         roof = None
-        if timed_kernels:
-            ms, meta = trace
-            n_s = len(sampled)
-            per_step = len(ms) // n_s
-            assert len(pairs) == per_step and per_step * n_s == len(ms), (len(pairs), per_step, len(ms))
-            flops_step = sum(2.0 * m * int(cin) * int(cout) for m, (cin, cout, _k, _v) in zip(pairs, meta[:per_step]))
-            ms_total = float(ms.astype("float64").sum())
-            if args.dump_conv:
-                us = 1e3 * ms.reshape(n_s, per_step).mean(0)
-                table = [dict(i=i, Cin=int(c[0]), Cout=int(c[1]), K=int(c[2]), Vout=int(c[3]), M=m, us=round(float(u), 1),
-                              tflops=round(2.0 * m * int(c[0]) * int(c[1]) / float(u) / 1e6, 2))
-                         for i, (m, c, u) in enumerate(zip(pairs, meta[:per_step], us))]
-                json.dump(table, open(args.dump_conv, "w"))
-            launches = len(ms)
-            flops_total = flops_step * n_s
-            achieved = flops_total / (ms_total * 1e-3) / 1e12
-            roof = {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                    "kernel": "k_spconv_sj<SR,NTW,W> (split-j; +k_spconv_scalar for the 4-channel stem): fp32 MFMA sparse "
-                              "conv, every launch of the sampled steps of the timed region",
-                    "launches": launches, "avg_launch_us": round(1e3 * ms_total / launches, 2),
-                    "flops_per_launch": round(flops_total / launches),
-                    "timed_steps": sampled,
-                    "share_of_step": round(ms_total * 1e-3 / n_s / (dt / args.steps), 4)}
+        if not args.no_kernel_events:
+            roof = conv_roofline(r, args)
             pmc = os.path.join(ROOT, "profiles", "conv_traffic.json")
-            if os.path.exists(pmc) and args.workload == "nuscenes_34k_w5" and args.cr == 1.0 and not args.fwd_only:
+            if os.path.exists(pmc) and args.cr == 1.0 and not args.fwd_only:
                 try:
-                    roof["traffic"] = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                    t = json.load(open(pmc))
+                    if t.get("workload") == name:
+                        roof["traffic"] = t.get("hbm_bytes_per_launch")
+                        roof["traffic_source"] = "profiles/conv_traffic.json (rocprofv3 --pmc passes of this command on " \
+                                                 "this workload; not re-measured in this run)"
                 except Exception:
                     pass
+            if world == 1 and not args.no_hbm_classes and not args.fwd_only:
+                roof["hbm_classes"] = hbm_classes(batch, w, step.hr)
+        others = None
+        if world == 1 and args.workload is None and not args.no_other_workloads and not args.fwd_only:
+            others = {}
+            for oname in ("nuscenes_34k_w5", "synthia_kitti_32k"):
+                ow = synth.workload(oname)
+                torch.manual_seed(1)
+                om = Net3DSeg(ow["C"], True, "SPVCNN", {"cr": args.cr}).to(dev)
+                ostep = LatteStep(om, ow["C"], hr_cfg_of(ow), side_stream=not args.no_side_stream)
+                ob = build_batch(ow, device=dev)
+                orr = time_steps(ostep, ob, args, 1, dev, backend, steps=max(5, args.steps // 2), warmup=2)
+                oroof = conv_roofline(orr, argparse.Namespace(dump_conv=None))
+                others[oname] = {"value": ob["n_points"] * orr["steps"] / orr["dt"], "unit": "points/s",
+                                 "ms_per_step": round(1e3 * orr["dt"] / orr["steps"], 3), "steps": orr["steps"],
+                                 "points_per_step": ob["n_points"], "voxels": ob["n_voxels"],
+                                 "conv_tflops": oroof["achieved"], "conv_frac_mfma": oroof["frac"]}
+                del om, ostep, ob
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(w, args.cr, args.cpu_scans)
         out = {
-            "metric": "points/sec per sparse-conv 3D fwd+ST-voxel TTA step" if not args.fwd_only else "points/sec, 3D fwd only",
-            "value": n_points * world * args.steps / dt, "unit": "points/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "metric": METRIC if not args.fwd_only else "points/sec, 3D fwd only",
+            "value": n_points_total * args.steps / dt, "unit": "points/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": args.workload, "scans_per_gpu": w["B"], "points_per_scan": w["n"], "classes": w["C"],
-                       "st_window": w["W"], "st_voxel_m": w["vs"], "max_range_m": w["R"], "spvcnn_cr": args.cr,
-                       "voxels_per_gpu": batch["n_voxels"], "parallelism": f"dp{world} (sequences sharded)"},
-            "host_issue_ms_per_step": round(1e3 * dt_host / args.steps, 3),
+            "config": {"workload": name, "scans_per_step": total_scans, "scans_per_gpu": w_rank["B"],
+                       "points_per_scan": w["n"], "classes": w["C"], "st_window": w["W"], "st_voxel_m": w["vs"],
+                       "max_range_m": w["R"], "spvcnn_cr": args.cr, "voxels_per_gpu": batch["n_voxels"],
+                       "parallelism": f"dp{world} (whole sequences per rank, no data-path collective"
+                                      + (", one flat RCCL all-reduce of the BatchNorm grads)" if world > 1 else ")"),
+                       **({"strong_scaling_base": "python bench.py --gpus 1 --workload multiseq_64"}
+                          if scaling == "strong" else {})},
+            "host_issue_ms_per_step": round(1e3 * r["dt_host"] / args.steps, 3),
             "roofline": roof, "cpu_baseline": cpu,
         }
+        if others is not None:
+            out["other_workloads"] = others
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -11,7 +11,8 @@ from torch.autograd import Function
 
 from . import ops
 
-__all__ = ["KernelMap", "get_kernel_offsets", "sparse_conv", "conv_bn", "batch_norm", "spvoxelize", "spdevoxelize"]
+__all__ = ["KernelMap", "get_kernel_offsets", "sparse_conv", "conv_bn", "batch_norm", "spvoxelize", "spdevoxelize",
+           "invalidate_packed", "bump_pack_epoch"]
 
 _OFFSET_CACHE: dict = {}
 
@@ -120,16 +121,72 @@ def _run_conv(feats, packed, kmap: KernelMap, use_reverse: bool, cout: int):
     return ops.spconv(feats, packed, kmap.results, cout, order=kmap.order())
 
 
+# Packed-weight cache invalidation.  A conv kernel's MFMA-fragment image is cached per module and re-made when the tag
+# (parameter version, data pointer, PACK_EPOCH) changes.  torch bumps `_version` for in-place ops on the parameter itself
+# (optimizer steps, load_state_dict's copy_), but NOT for writes through `.data` (the reference's update_ema_all /
+# create_ema_model: `ema_param.data[:] = ...`, latte/common/utils/ema_util.py:44-71,74-96; Conv3d.reset_parameters).
+# Those are covered by (a) Conv3d.invalidate_packed() in reset_parameters / _load_from_state_dict / _apply and
+# invalidate_packed(model) for callers, and (b) PACK_EPOCH: a global optimizer-step hook bumps it whenever an optimizer
+# that holds a sparse-conv kernel steps (TRAIN.UPDATE_PARAMS == "all": the EMA write to the teacher's kernels follows that
+# step, tools/latte.py:317-326), so every image is re-made once per iteration there and never in the norm-only mode.
+PACK_EPOCH = 0
+_KERNEL_IDS: dict = {}          # id(kernel parameter) -> weakref, filled by the first conv call on a kernel
+_OPT_HOLDS_KERNELS = None       # WeakKeyDictionary optimizer -> (n params, bool)
+
+
+def bump_pack_epoch() -> None:
+    """Declare every cached packed-weight image stale (call after writing conv kernels through `.data`)."""
+    global PACK_EPOCH
+    PACK_EPOCH += 1
+
+
+def invalidate_packed(model) -> None:
+    """Drop the packed-weight images of every sparse conv of `model`."""
+    for m in model.modules():
+        inv = getattr(m, "invalidate_packed", None)
+        if inv is not None:
+            inv()
+
+
+def _register_kernel(weight) -> None:
+    import weakref
+    k = id(weight)
+    if k not in _KERNEL_IDS:
+        _KERNEL_IDS[k] = weakref.ref(weight, lambda _r, k=k: _KERNEL_IDS.pop(k, None))
+        _install_optimizer_hook()
+
+
+def _install_optimizer_hook() -> None:
+    global _OPT_HOLDS_KERNELS
+    if _OPT_HOLDS_KERNELS is not None:
+        return
+    import weakref
+    from torch.optim.optimizer import register_optimizer_step_post_hook
+    _OPT_HOLDS_KERNELS = weakref.WeakKeyDictionary()
+
+    def post_step(opt, args, kwargs):
+        n = sum(len(g["params"]) for g in opt.param_groups)
+        hit = _OPT_HOLDS_KERNELS.get(opt)
+        if hit is None or hit[0] != n:
+            holds = any(id(p) in _KERNEL_IDS for g in opt.param_groups for p in g["params"])
+            _OPT_HOLDS_KERNELS[opt] = hit = (n, holds)
+        if hit[1]:
+            bump_pack_epoch()
+
+    register_optimizer_step_post_hook(post_step)
+
+
 def _packed(weight, mode: int, cache: dict | None):
     """MFMA-fragment image of `weight`, re-packed only when the parameter changed (under TRAIN.UPDATE_PARAMS == "norm"
-    the conv kernels are frozen: latte/common/utils/ema_util.py:16-24)."""
+    the conv kernels are frozen: latte/common/utils/ema_util.py:16-24); see PACK_EPOCH above for what "changed" covers."""
     w = weight if weight.dim() == 3 else weight.unsqueeze(0)
     if cache is None:
         return ops.pack_weights(w, mode)
-    tag = (weight._version, weight.data_ptr())
+    tag = (weight._version, weight.data_ptr(), PACK_EPOCH)
     hit = cache.get(mode)
     if hit is not None and hit[0] == tag:
         return hit[1]
+    _register_kernel(weight)
     packed = ops.pack_weights(w, mode)
     cache[mode] = (tag, packed)
     return packed

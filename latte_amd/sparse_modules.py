@@ -130,11 +130,36 @@ class Conv3d(nn.Module):
             s += ", transposed=True"
         return s
 
+    def invalidate_packed(self) -> None:
+        """drop the cached MFMA-fragment images of the kernel: required after writing the kernel through `.data`
+        (torch does not version those writes; see functional.PACK_EPOCH)"""
+        self._packed_cache.clear()
+
     def reset_parameters(self):
         std = 1.0 / math.sqrt((self.out_channels if self.transposed else self.in_channels) * self.kernel_volume)
         self.kernel.data.uniform_(-std, std)
         if self.bias is not None:
             self.bias.data.uniform_(-std, std)
+        self.invalidate_packed()
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self.invalidate_packed()
+        return super()._load_from_state_dict(*args, **kwargs)
+
+    def _apply(self, fn, *args, **kwargs):
+        self.invalidate_packed()
+        return super()._apply(fn, *args, **kwargs)
+
+    def __deepcopy__(self, memo):
+        # a copy (the EMA teacher, ema_util.create_ema_model) starts without packed images: its kernels get written
+        # through `.data` right after the copy
+        import copy
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = {} if k == "_packed_cache" else copy.deepcopy(v, memo)
+        return new
 
     def forward(self, input: SparseTensor) -> SparseTensor:
         return conv3d(input, self.kernel, self.bias, self.kernel_size, self.stride, self.dilation, self.transposed,

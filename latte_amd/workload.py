@@ -12,7 +12,7 @@ from . import synth
 from .quantize import quantize_scan_gpu
 from .tensor import SparseTensor
 
-__all__ = ["build_batch", "hr_cfg_of"]
+__all__ = ["build_batch", "hr_cfg_of", "build_conv_1m"]
 
 
 def hr_cfg_of(w: Dict) -> Dict:
@@ -44,8 +44,29 @@ def build_batch(w: Dict, device="cuda", scan_offset: int = 0, seed: int = 0) -> 
     g = torch.Generator(device="cpu").manual_seed(seed)
     l2s = (3 * torch.randn(n_fov, C, generator=g)).to(device).requires_grad_(True)
     l2t = (3 * torch.randn(n_fov, C, generator=g)).to(device)
+    ready = torch.cuda.Event()
+    ready.record(torch.cuda.current_stream())   # every input above was produced on this stream (LatteStep._ready_event)
     return {
+        "ready_event": ready,
         "lidar": lidar, "indices": indices, "inverse_map": inverse, "ori_points": ori, "pc2img_idx": fov,
         "img_indices": [torch.empty(int(m.sum()), 2) for m in fov], "pose": poses, "scene_name": scenes, "scan_ID": ids,
         "logit_2d_student": l2s, "logit_2d_teacher": l2t, "n_points": B * n, "n_voxels": int(lidar.C.shape[0]),
     }
+
+
+def build_conv_1m(device="cuda", min_voxels: int = 1_000_000, points_per_scan: int = 131072):
+    """BASELINE configs[4]: >= 1 M voxels from tiling config-3 scans: as many 131 072-point KITTI-like
+    scans as it takes, one batch index each, voxelized like the network's x0 (hash-ordered rows).  -> SparseTensor x0
+    (zero features; the micro-bench and its test bring their own)."""
+    from .point_voxel import initial_voxelize
+    from .tensor import PointTensor
+    coords, total, b = [], 0, 0
+    while total < min_voxels:
+        p, i = synth.make_scan(points_per_scan, b, beams=64, full_360=False)
+        c, _, _, _ = quantize_scan_gpu(torch.from_numpy(p).to(device), torch.from_numpy(i).to(device))
+        coords.append(torch.cat([c, torch.full((c.shape[0], 1), b, dtype=torch.int32, device=device)], 1))
+        total += c.shape[0]
+        b += 1
+    C4 = torch.cat(coords, 0)
+    z = PointTensor(torch.zeros(C4.shape[0], 4, device=device), C4.float())
+    return initial_voxelize(z, 0.05, 0.05)

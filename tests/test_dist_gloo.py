@@ -66,3 +66,62 @@ def test_ranks_own_disjoint_sequences():
     assert all(ids[a].isdisjoint(ids[b]) for a in range(8) for b in range(a + 1, 8))
     # a rank's scans form whole sequences: B is a multiple of the sequence length
     assert w["B"] % w["seq_len"] == 0
+
+
+def _shard_worker(rank, world, port, out):
+    """what bench.py --gpus N does with BASELINE configs[3] (multiseq_64), minus the GPU: every rank derives its scans from
+    shard_sequences, builds the per-scan metadata like latte_amd.workload.build_batch, and the ranks compare notes"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from latte_amd import synth
+    from latte_amd.tta_step import shard_sequences
+    w = synth.workload("multiseq_64")
+    L = w["seq_len"]
+    n_seq = w["B"] // L
+    s0, ns = shard_sequences(n_seq, world, rank)
+    scans = list(range(s0 * L, (s0 + ns) * L))
+    scenes = [f"scene-{1000 + g // L:04d}" for g in scans]
+    ids = [g % L for g in scans]
+    mine = dict(scans=scans, scenes=scenes, ids=ids)
+    allr = [None] * world
+    dist.all_gather_object(allr, mine)
+    ok = True
+    every = [g for r in allr for g in r["scans"]]
+    ok = ok and sorted(every) == list(range(w["B"])) and len(set(every)) == w["B"]      # disjoint, complete
+    for r in allr:                                                                        # whole sequences only
+        for sc in set(r["scenes"]):
+            fr = sorted(i for s, i in zip(r["scenes"], r["ids"]) if s == sc)
+            ok = ok and fr == list(range(L))
+    for a in range(world):
+        for b in range(a + 1, world):
+            ok = ok and set(allr[a]["scenes"]).isdisjoint(allr[b]["scenes"])              # no scene on two ranks
+    # HR_Block's window rule (latte/models/hr_module.py:192-195) never reaches another rank's frames
+    from latte_amd.hr_module import HR_Block
+    from latte_amd.workload import hr_cfg_of
+    hr = HR_Block(**hr_cfg_of(w))
+    fake = dict(scene_name=scenes, scan_ID=ids, ori_points=[torch.zeros(1, 3)] * len(scans))
+    segs, _, _ = hr._plan(fake, "ori_points", fake, "ori_points")
+    ok = ok and all(scenes[i] == scenes[j] and abs(ids[i] - ids[j]) <= w["W"] // 2 for i, j, _, _ in segs)
+    want = sum(min(L - 1, i + w["W"] // 2) - max(0, i - w["W"] // 2) + 1 for i in range(L)) * ns
+    ok = ok and len(segs) == want
+    out[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_multiseq_64_shard_gives_each_rank_whole_sequences_gloo(world):
+    with mp.Manager() as m:
+        out = m.dict()
+        mp.spawn(_shard_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+        assert dict(out) == {r: True for r in range(world)}
+
+
+def test_shard_sequences_covers_every_world_size():
+    from latte_amd.tta_step import shard_sequences
+    for world in range(1, 9):
+        runs = [shard_sequences(8, world, r) for r in range(world)]
+        assert sum(n for _, n in runs) == 8 and all(n >= 1 for _, n in runs)
+        assert all(runs[r][0] + runs[r][1] == runs[r + 1][0] for r in range(world - 1)) and runs[0][0] == 0
+    with pytest.raises(ValueError):
+        shard_sequences(8, 2, 2)
