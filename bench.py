@@ -105,8 +105,9 @@ def cpu_baseline(w, cr, n_scans=None):
     import torch
     all_cores = int(torch.get_num_threads())
     if n_scans is None:
-        # ~20 s of CPU work in total over the two legs: the oracle runs ~12-15 k points/s on 16 threads
-        n_scans = max(1, min(w["B"], int(round(110_000 / w["n"]))))
+        # the step's whole batch when that is <= ~1 M points (measured on the GPU box: ~40 k points/s on 16 threads, ~34 k on
+        # 4 -> ~20 s + ~24 s for the 6 x 131 072-point batch), else as many whole scans as fit 1 M points
+        n_scans = max(1, min(w["B"], 1_000_000 // w["n"]))
     full = _cpu_leg(w, cr, n_scans, all_cores)
     omp4 = _cpu_leg(w, cr, n_scans, min(4, all_cores))
     torch.set_num_threads(all_cores)

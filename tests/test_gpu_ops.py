@@ -504,3 +504,59 @@ def test_gather_rows_backward_matches_torch_indexing():
     assert torch.equal(got, want)
     with torch.no_grad():
         assert torch.equal(gather_rows(x, idx), x[idx])
+
+
+def test_packed_weight_cache_follows_every_way_a_kernel_changes(scans_small):
+    """The MFMA-fragment image of a conv kernel is cached per module (functional._packed).  torch versions in-place ops on
+    the parameter, but not writes through `.data` (the reference's update_ema_all / create_ema_model and
+    Conv3d.reset_parameters write that way: latte/common/utils/ema_util.py:44-96): those need invalidate_packed(), and an
+    optimizer that holds conv kernels (TRAIN.UPDATE_PARAMS == "all") declares every image stale when it steps."""
+    from copy import deepcopy
+    from latte_amd import functional as LF
+    from latte_amd import sparse_modules as spnn
+    from latte_amd.tensor import SparseTensor
+    coords = torch.from_numpy(scans_small["coords"]).cuda()
+    g = torch.Generator().manual_seed(3)
+    feats = torch.randn(coords.shape[0], 32, generator=g).cuda()
+
+    def run(conv):
+        x = SparseTensor(feats, coords, 1)
+        with torch.no_grad():
+            return conv(x).feats.clone()
+
+    conv = spnn.Conv3d(32, 48, 3).cuda()
+    conv.kernel.requires_grad_(False)
+    y0 = run(conv)
+    assert conv._packed_cache                                   # an image is cached now
+    conv.kernel.data.mul_(2.0)                                  # unversioned write ...
+    conv.invalidate_packed()                                    # ... declared by the writer
+    assert torch.allclose(run(conv), 2 * y0, rtol=1e-6, atol=1e-7)
+    with torch.no_grad():
+        conv.kernel.mul_(0.5)                                   # versioned in-place op: seen without help
+    assert torch.allclose(run(conv), y0, rtol=1e-6, atol=1e-7)
+    sd = {k: v.clone() * 3 for k, v in conv.state_dict().items()}
+    conv.load_state_dict(sd)                                    # checkpoint load after a first forward
+    assert torch.allclose(run(conv), 3 * y0, rtol=1e-6, atol=1e-6)
+    conv.reset_parameters()                                     # re-initialisation
+    want = LF.sparse_conv(feats, conv.kernel.detach(), spnn.build_kernel_map(SparseTensor(feats, coords, 1), 3, 1, 1)[0])
+    assert torch.equal(run(conv), want)
+    # teacher/student pair, everything trainable: the teacher's kernel is written through .data after the student's
+    # optimizer step (tools/latte.py:317-326); the step itself declares the cached images stale
+    student = spnn.Conv3d(32, 48, 3).cuda()
+    teacher = deepcopy(student)
+    for p in teacher.parameters():
+        p.detach_()
+    yt0 = run(teacher)
+    opt = torch.optim.SGD(student.parameters(), lr=0.5)
+    x = SparseTensor(feats, coords, 1)
+    student(x).feats.square().mean().backward()
+    opt.step()
+    ys = run(student)
+    assert not torch.allclose(ys, yt0)
+    for pt, ps in zip(teacher.parameters(), student.parameters()):
+        pt.data[:] = 0.0 * pt[:].data[:] + 1.0 * ps[:].data[:]  # update_ema_all with alpha = 0
+    assert torch.equal(run(teacher), ys)
+    # module-tree helper
+    teacher.kernel.data.mul_(2.0)
+    LF.invalidate_packed(torch.nn.Sequential(teacher))
+    assert torch.allclose(run(teacher), 2 * ys, rtol=1e-6, atol=1e-7)

@@ -2,15 +2,15 @@
 # rocprofv3 evidence for the round: kernel-trace stats of the bench command, then two PMC passes (HBM read / write bytes).
 # usage (on the GPU box): bash tools/profile_round.sh r01
 set -e
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 mkdir -p $R/gpurun_out/prof_$TAG
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$TAG -o kt -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof_$TAG/kt.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$TAG -o kt -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-workloads --no-hbm-classes > $R/gpurun_out/prof_$TAG/kt.log 2>&1
 cp /tmp/kt_$TAG/kt_kernel_stats.csv $R/gpurun_out/prof_$TAG/${TAG}_kernel_stats.csv
 grep -v "^[WEI]2026" $R/gpurun_out/prof_$TAG/kt.log | tail -1 > $R/gpurun_out/prof_$TAG/${TAG}_bench_under_rocprof.json
-timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pf_$TAG -o pf -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events > $R/gpurun_out/prof_$TAG/pf.log 2>&1
-timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pw_$TAG -o pw -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events > $R/gpurun_out/prof_$TAG/pw.log 2>&1
+timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pf_$TAG -o pf -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-workloads --no-hbm-classes --no-kernel-events > $R/gpurun_out/prof_$TAG/pf.log 2>&1
+timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pw_$TAG -o pw -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-workloads --no-hbm-classes --no-kernel-events > $R/gpurun_out/prof_$TAG/pw.log 2>&1
 python - <<PY
 import csv, collections, json
 out = {}
@@ -29,7 +29,7 @@ n = sum(out["FETCH_SIZE"][k]["dispatches"] for k in conv)
 f = sum(out["FETCH_SIZE"][k]["sum"] for k in conv)
 w = sum(out["WRITE_SIZE"].get(k, {"sum": 0})["sum"] for k in conv)
 print("conv dispatches", n, "FETCH_SIZE/dispatch", f / n, "WRITE_SIZE/dispatch", w / n)
-json.dump({"hbm_bytes_per_launch": round((2 * f / n + w / n) * 1024), "fetch_size_kb_per_launch_raw": f / n,
+json.dump({"workload": "a2d2_kitti_128k", "hbm_bytes_per_launch": round((2 * f / n + w / n) * 1024), "fetch_size_kb_per_launch_raw": f / n,
            "write_size_kb_per_launch": w / n,
            "correction": "FETCH_SIZE doubled (gfx950 reports half the bytes of 16-B/lane reads, MI355X_MICROARCH.md #HBM); "
                          "WRITE_SIZE as reported; KB -> bytes x1024",
