@@ -206,9 +206,9 @@ def hbm_classes(batch, w, hr):
         "lt_softmax_entropy [P,C_cls]: 8PC + 4P")
     probs, _ = ops.softmax_entropy(logits)
     E, Vt = int(geo["h_selem"].numel()), int(geo["h_seg"].numel()) - 1
-    add("segment_reduce", _event_us(lambda: ops.segment_reduce(probs, geo["h_selem"], geo["h_seg"], "mean", src_index=geo["h_src"])),
-        4 * E * C + 8 * E + 4 * Vt * C + 4 * Vt,
-        "lt_segment_reduce mean of hist probabilities over ST voxels: 4E*C (gathered rows) + 8E (two indices) + 4Vt*C + 4Vt")
+    add("segment_reduce", _event_us(lambda: ops.segment_reduce(probs, geo["h_row"], geo["h_seg"], "mean")),
+        4 * E * C + 4 * E + 4 * Vt * C + 4 * Vt,
+        "lt_segment_reduce mean of hist probabilities over ST voxels: 4E*C (gathered rows) + 4E (row index) + 4Vt*C + 4Vt")
     a_keys, h_keys = None, None
     # the join's inputs are the sorted unique keys of both sides: rebuild them the way geometry() does
     pts = torch.cat([p.reshape(-1, 3) for p in batch["ori_points"]], 0).float()
@@ -216,9 +216,12 @@ def hbm_classes(batch, w, hr):
     import numpy as np
     st = torch.as_tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int64, device=dev)
     anc = torch.arange(len(sizes), dtype=torch.int32, device=dev)
-    keys, _ = ops.st_keys(pts, st, st[:-1].contiguous(), anc, None, int(pts.shape[0]), hr.max_range, hr.voxel_size, hr.min_offset)
-    _, _, a_uk, _ = ops.sort_segments(keys)
-    add("sort_segments", _event_us(lambda: ops.sort_segments(keys)), 8 * P + 8 * P + 12 * int(a_uk.numel()),
+    cb = ops.st_coord_bits(hr.max_range, hr.voxel_size)
+    kb = 3 * cb + max(1, (len(sizes) - 1).bit_length())
+    keys, _ = ops.st_keys(pts, st, st[:-1].contiguous(), anc, None, int(pts.shape[0]), hr.max_range, hr.voxel_size,
+                          hr.min_offset, cb)
+    _, _, a_uk, _ = ops.sort_segments(keys, kb)
+    add("sort_segments", _event_us(lambda: ops.sort_segments(keys, kb)), 8 * P + 8 * P + 12 * int(a_uk.numel()),
         "lt_sort_segments of the anchor keys (radix sort + segment heads): 8P keys + 8P (sorted elem, inverse) + 12V")
     add("st_join", _event_us(lambda: ops.st_join(a_uk, a_uk)), 8 * 2 * int(a_uk.numel()),
         "lt_st_join of two sorted voxel-key sets: 8(Va + Vt)")

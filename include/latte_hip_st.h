@@ -19,14 +19,18 @@ int lt_softmax_bwd(const float* probs, const float* gprobs, int64_t P, int32_t C
  * Segment s covers elements [seg_out_start[s], seg_out_start[s+1]) = points[seg_src_start[s] ...] of one frame,
  * belongs to anchor seg_anchor[s] and is transformed by the row-major 3x4 fp64 matrix seg_T + 12*s
  * (seg_T == NULL: no transform, the fp32 range test of the anchor branch :227 is used).
- * key = anchor<<48 | x<<32 | y<<16 | z with (x,y,z) = floor(p/voxel_size) - min_offset, or INT64_MAX when the point
- * is outside max_range.  src[e] = index of the source point.  All seg_* arrays are DEVICE arrays. */
+ * key = anchor<<3b | x<<2b | y<<b | z (dense: b = coord_bits in [1,16], 2*max_range/voxel_size + 4 < 2^b) with
+ * (x,y,z) = floor(p/voxel_size) - min_offset, or INT64_MAX when the point is outside max_range.  Dense keys are what
+ * makes the sort cheap: anchors x 3b bits instead of 63 (lt_sort_segments' key_bits).  src[e] = index of the source
+ * point.  All seg_* arrays are DEVICE arrays. */
 int lt_st_keys(const float* points, const int64_t* seg_out_start, const int64_t* seg_src_start,
                const int32_t* seg_anchor, const double* seg_T, int32_t S, int64_t E, double max_range,
-               double voxel_size, int32_t min_offset, int64_t* keys, int32_t* src, lt_stream_t stream);
+               double voxel_size, int32_t min_offset, int32_t coord_bits, int64_t* keys, int32_t* src,
+               lt_stream_t stream);
 
 /* np.unique(keys, return_index, return_inverse) as a sort: one stable radix sort of (key, element) pairs, then
- * segment heads.  Keys equal to INT64_MAX are "masked" and belong to no voxel.
+ * segment heads.  Keys equal to INT64_MAX are "masked" and belong to no voxel.  key_bits: every unmasked key is
+ * < 2^key_bits (the sort then runs over key_bits + 1 bits); <= 0 or >= 62: all 63 bits.
  * Outputs (device): sorted_elem[E]; inverse[E] (voxel id or -1); uniq_keys[cap E]; seg_start[cap E+1]
  * (positions in sorted order, seg_start[V] = number of unmasked elements).  *V (HOST).  [sync] */
 int64_t lt_sort_segments_workspace_bytes(int64_t E);

@@ -77,7 +77,7 @@ SIGNATURES = {
     # include/latte_hip_st.h
     "lt_softmax_entropy": (ctypes.c_int, [P, I64, I32, P, P, P]),
     "lt_softmax_bwd": (ctypes.c_int, [P, P, I64, I32, P, P]),
-    "lt_st_keys": (ctypes.c_int, [P, P, P, P, P, I32, I64, F64, F64, I32, P, P, P]),
+    "lt_st_keys": (ctypes.c_int, [P, P, P, P, P, I32, I64, F64, F64, I32, I32, P, P, P]),
     "lt_sort_segments_workspace_bytes": (I64, [I64]),
     "lt_sort_segments": (ctypes.c_int, [P, I64, I32, P, I64, P, P, P, P, PI64, P]),
     "lt_segment_reduce": (ctypes.c_int, [P, I32, P, P, P, I64, I32, P, P, P]),

@@ -123,25 +123,50 @@ extern "C" int lt_spcount(const int32_t* idx, int64_t n, int32_t* out, int64_t n
 }
 
 // ---------------------------------------------------------------- unique + sort
-// wave64 ballot compaction of the occupied slots: one global atomic per wave.
-__global__ void k_table_compact(LtTable t, uint64_t* __restrict__ out_keys, int* __restrict__ out_vals,
-                                unsigned int* __restrict__ counter) {
+// wave64 ballot compaction of the occupied slots.  A 256-thread block owns LT_COMPACT_ITEMS x 256 consecutive slots
+// (coalesced 8-B reads), counts its occupied slots with ballots, reserves its output range with ONE global atomic and
+// hands the waves their sub-ranges through LDS -- one atomic per 2048 slots instead of one per 64 (at one per wave the
+// kernel ran at 0.08 TB/s: every wave of the grid serialised on the same counter).  Output order is arbitrary (the
+// unique keys are radix-sorted afterwards).
+#define LT_COMPACT_ITEMS 8
+__global__ __launch_bounds__(256) void k_table_compact(LtTable t, uint64_t* __restrict__ out_keys, int* __restrict__ out_vals,
+                                                       unsigned int* __restrict__ counter) {
+  __shared__ unsigned int s_wave[4];
+  __shared__ unsigned int s_base;
   const int64_t cap = (int64_t)t.mask + 1;
-  const int lane = threadIdx.x & 63;
-  // cap is a power of two >= 1024 and blockDim is 256: every wave runs the same trip count
-  for (int64_t base = blockIdx.x * (int64_t)blockDim.x; base < cap; base += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t s = base + threadIdx.x;
-    const uint64_t k = t.keys[s];
-    const bool occ = (k != LT_EMPTY_KEY);
-    const unsigned long long m = __ballot(occ);
-    unsigned int off = 0;
-    if (lane == 0 && m) off = atomicAdd(counter, (unsigned int)__popcll(m));
-    off = __shfl(off, 0);
-    if (occ) {
-      const unsigned int pos = off + (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
-      out_keys[pos] = k;
-      out_vals[pos] = t.vals[s];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t chunk = (int64_t)LT_COMPACT_ITEMS * 256;
+  // cap is a power of two >= 1024: every thread of a block runs the same trip count
+  for (int64_t base = blockIdx.x * chunk; base < cap; base += (int64_t)gridDim.x * chunk) {
+    uint64_t k[LT_COMPACT_ITEMS];
+    unsigned long long m[LT_COMPACT_ITEMS];
+    unsigned int wave_total = 0;
+#pragma unroll
+    for (int it = 0; it < LT_COMPACT_ITEMS; ++it) {
+      const int64_t s = base + it * 256 + threadIdx.x;
+      k[it] = s < cap ? t.keys[s] : LT_EMPTY_KEY;
+      m[it] = __ballot(k[it] != LT_EMPTY_KEY);
+      wave_total += (unsigned int)__popcll(m[it]);
     }
+    if (lane == 0) s_wave[wave] = wave_total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned int tot = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+      s_base = tot ? atomicAdd(counter, tot) : 0u;
+    }
+    __syncthreads();
+    unsigned int off = s_base;
+    for (int w = 0; w < wave; ++w) off += s_wave[w];
+#pragma unroll
+    for (int it = 0; it < LT_COMPACT_ITEMS; ++it) {
+      if (k[it] != LT_EMPTY_KEY) {
+        const unsigned int pos = off + (unsigned int)__popcll(m[it] & ((1ull << lane) - 1ull));
+        out_keys[pos] = k[it];
+        out_vals[pos] = t.vals[base + it * 256 + threadIdx.x];
+      }
+      off += (unsigned int)__popcll(m[it]);
+    }
+    __syncthreads();  // s_wave / s_base are rewritten by the next chunk
   }
 }
 
@@ -208,7 +233,7 @@ extern "C" int lt_unique_sorted(const int64_t* keys, int64_t n, int32_t key_bits
   hipLaunchKernelGGL(k_table_insert, dim3(lt_grid(n, 256)), dim3(256), 0, stream, keys, n, t);
   LT_LAUNCH_CHECK();
   const int64_t cap = (int64_t)t.mask + 1;
-  hipLaunchKernelGGL(k_table_compact, dim3(lt_grid(cap, 256)), dim3(256), 0, stream, t, ck, cv, counter);
+  hipLaunchKernelGGL(k_table_compact, dim3(lt_grid(cap / LT_COMPACT_ITEMS, 256)), dim3(256), 0, stream, t, ck, cv, counter);
   LT_LAUNCH_CHECK();
   unsigned int v_host = 0;
   LT_CHECK_HIP(hipMemcpyAsync(&v_host, counter, 4, hipMemcpyDeviceToHost, stream));

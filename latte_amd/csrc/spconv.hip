@@ -1153,7 +1153,7 @@ static void launch_sj_one(const PlanArgs& a, hipStream_t stream) {
   LT_CONV_LAUNCH((k_spconv_sj<SR, NTW, W>), dim3(total), dim3(64 * W), stream, b);
 }
 
-// split-j launch: sr in {1,2,4}, ntw in {2,3,4}, w in {2,3,4,6,8}; needs (Cin/16) % w == 0 and Cin <= LT_ZERO_ROW
+// split-j launch: sr in {1,2,4}, ntw in {2,3,4}, w in {2,3,4,6,8}; needs (Cin/16) % w == 0
 static bool sj_supported(int Cin, int sr, int ntw, int w) {
   return (sr == 1 || sr == 2 || sr == 4) && (ntw == 2 || ntw == 3 || ntw == 4) &&
          (w == 2 || w == 3 || w == 4 || w == 6 || w == 8) && (Cin / 16) % w == 0;
@@ -1254,6 +1254,12 @@ extern "C" int64_t lt_conv_timer_end(float* ms, int32_t* meta, int64_t capacity)
 // 4 column tiles per wave (3 for Cout = 48, 96, ...), and the channel groups of an offset split over W = 2 waves, or 4
 // when 2 would leave fewer than 7000 waves or the input is 256 channels or wider.  The split-j kernel runs it whenever W
 // divides Cin/16; other widths take the flat split-k loop with the same shape.
+// Rows per workgroup: 16 (one strip), or 32 (two strips per wave: every weight fragment a wave loads feeds two strips) on
+// levels with enough rows that the coarser work items still fill the chip many times over -- measured per level at the
+// a2d2_kitti_128k sizes (tools/cb_a2d2.sh): 310 k rows, C=96: 377 -> 349 us; 141 k rows: 173 -> 164 us; below ~100 k rows
+// the shorter tail of 16-row workgroups wins.  A function of Vout only: lt_spconv_stat_blocks must agree with it.
+static int conv_default_sr(int64_t Vout) { return Vout >= 100000 ? 2 : 1; }
+
 struct LtConvShape {
   int sr, ntw, w;
   bool sj;
@@ -1263,8 +1269,8 @@ static LtConvShape conv_default_shape(int64_t Vin, int64_t Vout, int Cin, int Co
   const int ntt = Cout / 16, J = Cin / 16;
   LtConvShape s;
   s.ntw = ntt % 4 == 0 ? 4 : ntt % 3 == 0 ? 3 : ntt % 2 == 0 ? 2 : 1;
-  s.sr = 1;
-  const int64_t waves2 = ((Vout + 15) / 16) * (ntt / s.ntw) * 2;
+  s.sr = conv_default_sr(Vout);
+  const int64_t waves2 = ((Vout + 16 * s.sr - 1) / (16 * s.sr)) * (ntt / s.ntw) * 2;
   s.w = (waves2 >= 7000 && J < 16) ? 2 : 4;
   if (J % s.w != 0 && J % 2 == 0) s.w = 2;
   s.sj = s.ntw >= 2 && sj_supported(Cin, s.sr, s.ntw, s.w) && Vin * Cin * 4 < 0x7FFFF000ll &&
@@ -1279,7 +1285,7 @@ static int64_t rf_grid_x(int64_t Vout, int sr) {
 
 extern "C" int64_t lt_spconv_stat_blocks(int64_t Vout, int32_t Cout) {
   if (Vout <= 0 || Cout < 16) return 0;
-  return rf_grid_x(Vout, 1);  // every default shape has 16-row workgroups
+  return rf_grid_x(Vout, conv_default_sr(Vout));
 }
 
 extern "C" int64_t lt_spconv_stats_bytes(int64_t Vout, int32_t Cout) {

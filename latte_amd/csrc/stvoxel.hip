@@ -72,8 +72,9 @@ extern "C" int lt_softmax_bwd(const float* probs, const float* gprobs, int64_t P
 // ---------------------------------------------------------------- transform + range + key
 __global__ void k_st_keys(const float* __restrict__ pts, const int64_t* __restrict__ seg_out, const int64_t* __restrict__ seg_src,
                           const int* __restrict__ seg_anchor, const double* __restrict__ seg_T, int S, int64_t E,
-                          double R, double vs, int min_off, int64_t* __restrict__ keys, int* __restrict__ src) {
+                          double R, double vs, int min_off, int cb, int64_t* __restrict__ keys, int* __restrict__ src) {
 #pragma clang fp contract(off)
+  const int64_t cmask = (1ll << cb) - 1;
   for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
     // segment of e: largest s with seg_out[s] <= e  (S is small: <= anchors x window)
     int lo = 0, hi = S - 1;
@@ -100,8 +101,8 @@ __global__ void k_st_keys(const float* __restrict__ pts, const int64_t* __restri
     int64_t key = ST_MASKED;
     if (in_range) {
       const int cx = (int)floor(x / vs) - min_off, cy = (int)floor(y / vs) - min_off, cz = (int)floor(z / vs) - min_off;
-      key = ((int64_t)seg_anchor[s] << 48) | ((int64_t)(cx & 0xFFFF) << 32) | ((int64_t)(cy & 0xFFFF) << 16) |
-            (int64_t)(cz & 0xFFFF);
+      key = ((int64_t)seg_anchor[s] << (3 * cb)) | (((int64_t)cx & cmask) << (2 * cb)) | (((int64_t)cy & cmask) << cb) |
+            ((int64_t)cz & cmask);
     }
     keys[e] = key;
     src[e] = (int)j;
@@ -110,16 +111,18 @@ __global__ void k_st_keys(const float* __restrict__ pts, const int64_t* __restri
 
 extern "C" int lt_st_keys(const float* points, const int64_t* seg_out_start, const int64_t* seg_src_start,
                           const int32_t* seg_anchor, const double* seg_T, int32_t S, int64_t E, double max_range,
-                          double voxel_size, int32_t min_offset, int64_t* keys, int32_t* src, hipStream_t stream) {
+                          double voxel_size, int32_t min_offset, int32_t coord_bits, int64_t* keys, int32_t* src,
+                          hipStream_t stream) {
   LT_REQUIRE(S >= 0 && E >= 0 && E < INT_MAX, LT_ERR_RANGE, "lt_st_keys: bad sizes");
   if (E == 0) return LT_OK;
   LT_REQUIRE(S >= 1 && points && seg_out_start && seg_src_start && seg_anchor && keys && src, LT_ERR_ARG,
              "lt_st_keys: null pointer");
   LT_REQUIRE(voxel_size > 0 && max_range > 0, LT_ERR_ARG, "lt_st_keys: voxel_size and max_range must be positive");
-  LT_REQUIRE(2.0 * max_range / voxel_size + 4.0 < 65536.0, LT_ERR_RANGE,
-             "lt_st_keys: max_range/voxel_size too large for 16-bit voxel coordinates");
+  LT_REQUIRE(coord_bits >= 1 && coord_bits <= 16, LT_ERR_ARG, "lt_st_keys: coord_bits=%d must be in [1,16]", coord_bits);
+  LT_REQUIRE(2.0 * max_range / voxel_size + 4.0 < (double)(1 << coord_bits), LT_ERR_RANGE,
+             "lt_st_keys: max_range/voxel_size too large for %d-bit voxel coordinates", coord_bits);
   hipLaunchKernelGGL(k_st_keys, dim3(lt_grid(E, 256)), dim3(256), 0, stream, points, seg_out_start, seg_src_start,
-                     seg_anchor, seg_T, S, E, max_range, voxel_size, min_offset, keys, src);
+                     seg_anchor, seg_T, S, E, max_range, voxel_size, min_offset, coord_bits, keys, src);
   LT_LAUNCH_CHECK();
   return LT_OK;
 }
@@ -189,7 +192,9 @@ extern "C" int lt_sort_segments(const int64_t* keys, int64_t E, int32_t key_bits
   if (E == 0) return LT_OK;
   LT_REQUIRE(keys && ws && sorted_elem && inverse && uniq_keys && seg_start, LT_ERR_ARG, "lt_sort_segments: null pointer");
   LT_REQUIRE(ws_bytes >= lt_sort_segments_workspace_bytes(E), LT_ERR_WORKSPACE, "lt_sort_segments: workspace too small");
-  (void)key_bits;  // masked elements carry INT64_MAX, so all 63 bits take part in the sort
+  // valid keys are < 2^key_bits (caller's promise); masked elements carry INT64_MAX, whose bits [0, key_bits] are all ones:
+  // a sort over key_bits + 1 bits puts them last, and costs ceil((key_bits + 1) / 8) radix passes instead of 8
+  const unsigned end_bit = (key_bits >= 1 && key_bits < 62) ? (unsigned)key_bits + 1u : 63u;
   LtArena a(ws, ws_bytes);
   int64_t* skeys = (int64_t*)a.take(E * 8);
   int* iota = (int*)a.take(E * 4);
@@ -203,7 +208,7 @@ extern "C" int lt_sort_segments(const int64_t* keys, int64_t E, int32_t key_bits
   LT_LAUNCH_CHECK();
   size_t sbs = (size_t)sb, cbs = (size_t)cb;
   // LSD radix sort is stable: equal keys keep ascending element order => segment head = first occurrence
-  LT_CHECK_HIP(rocprim::radix_sort_pairs<LtSortConfig>(stmp, sbs, keys, skeys, iota, sorted_elem, (size_t)E, 0, 63, stream));
+  LT_CHECK_HIP(rocprim::radix_sort_pairs<LtSortConfig>(stmp, sbs, keys, skeys, iota, sorted_elem, (size_t)E, 0, end_bit, stream));
   auto it = rocprim::make_transform_iterator(rocprim::counting_iterator<int>(0), HeadFlag{skeys});
   LT_CHECK_HIP(rocprim::inclusive_scan(ctmp, cbs, it, vid, (size_t)E, rocprim::plus<int>(), stream));
   hipLaunchKernelGGL(k_emit_segments, dim3(lt_grid(E, 256)), dim3(256), 0, stream, skeys, sorted_elem, vid, E, inverse,
@@ -217,6 +222,8 @@ extern "C" int lt_sort_segments(const int64_t* keys, int64_t E, int32_t key_bits
 }
 
 // ---------------------------------------------------------------- segmented reduce
+// one thread per (voxel, class): the C lanes of a voxel read its rows coalesced; four points of the segment are in flight
+// per thread (independent index -> row chains), accumulated in ascending point order
 __global__ void k_segment_reduce(const float* __restrict__ src, int C, const int* __restrict__ src_index,
                                  const int* __restrict__ selem, const int* __restrict__ seg_start, int64_t V, int mode,
                                  float* __restrict__ out, int* __restrict__ argmax) {
@@ -227,7 +234,24 @@ __global__ void k_segment_reduce(const float* __restrict__ src, int C, const int
     const int p0 = seg_start[v], p1 = seg_start[v + 1];
     float acc = mode == 2 ? -INFINITY : 0.f;
     int arg = -1;
-    for (int p = p0; p < p1; ++p) {
+    int p = p0;
+    for (; p + 3 < p1; p += 4) {
+      int e[4];
+      int64_t row[4];
+      float x[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) e[i] = selem[p + i];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) row[i] = src_index ? src_index[e[i]] : e[i];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) x[i] = src[row[i] * C + c];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (mode == 2) { if (x[i] > acc || arg < 0) { acc = x[i]; arg = e[i]; } }
+        else acc += x[i];
+      }
+    }
+    for (; p < p1; ++p) {
       const int e = selem[p];
       const int64_t row = src_index ? src_index[e] : e;
       const float x = src[row * C + c];

@@ -73,8 +73,10 @@ def _scene_id(s) -> int:
     return int(s.split("-")[-1]) if "-" in s else int(s)
 
 
-def _decode_xyz(keys: torch.Tensor) -> torch.Tensor:
-    return torch.stack([(keys >> 32) & 0xFFFF, (keys >> 16) & 0xFFFF, keys & 0xFFFF], 1).to(torch.int32)
+def _decode_xyz(keys: torch.Tensor, cb: int) -> torch.Tensor:
+    """voxel coordinates out of dense ST keys (anchor << 3cb | x << 2cb | y << cb | z)"""
+    m = (1 << cb) - 1
+    return torch.stack([(keys >> (2 * cb)) & m, (keys >> cb) & m, keys & m], 1).to(torch.int32)
 
 
 class _HRResult(dict):
@@ -163,27 +165,34 @@ class HR_Block(nn.Module):
         a_seg_anchor_d = torch.arange(B, dtype=torch.int32, device=dev)
 
         # ---- keys, sort, segments
+        # dense keys: anchor bits on top of 3 x cb coordinate bits -> the radix sorts run over key_bits + 1 bits
+        # (a2d2: 3 + 30, nuScenes: 3 + 27) instead of 63
+        cb = ops.st_coord_bits(self.max_range, self.voxel_size)
+        key_bits = 3 * cb + max(1, (B - 1).bit_length())
         h_keys, h_src = ops.st_keys(h_pts, seg_out_d, seg_src_d, seg_anchor_d, seg_T_d, E, self.max_range,
-                                    self.voxel_size, self.min_offset)
+                                    self.voxel_size, self.min_offset, cb)
         a_keys, _ = ops.st_keys(a_pts, a_seg_out_d, a_seg_out_d[:-1].contiguous(), a_seg_anchor_d, None, Pa,
-                                self.max_range, self.voxel_size, self.min_offset)
-        h_selem, h_inv, h_uk, h_seg = ops.sort_segments(h_keys)
-        a_selem, a_inv, a_uk, a_seg = ops.sort_segments(a_keys)
+                                self.max_range, self.voxel_size, self.min_offset, cb)
+        h_selem, h_inv, h_uk, h_seg = ops.sort_segments(h_keys, key_bits)
+        a_selem, a_inv, a_uk, a_seg = ops.sort_segments(a_keys, key_bits)
 
         # ---- correspondence
         a_sel, t_sel = ops.st_join(a_uk, h_uk)
         a_sel_l, t_sel_l = a_sel.long(), t_sel.long()
         matched_keys = a_uk[a_sel_l]
-        per_anchor = torch.bincount((matched_keys >> 48), minlength=B).tolist()
+        per_anchor = torch.bincount((matched_keys >> (3 * cb)), minlength=B).tolist()
         if min(per_anchor) == 0:
             print("No correspondence found!")
             raise AssertionError
         ac_first = a_selem[a_seg[:-1].long()].long()            # first in-range point of each anchor voxel
         tr_first = h_src[h_selem[h_seg[:-1].long()].long()].long()  # ... of each hist voxel, as hist point index
-        return dict(Ph=Ph, Pa=Pa, B=B, h_src=h_src, h_selem=h_selem, h_inv=h_inv, h_seg=h_seg, a_selem=a_selem,
+        # source row of every sorted hist element, composed once: the two segmented means of forward() then follow
+        # seg_start -> row -> probs instead of seg_start -> sorted_elem -> h_src -> probs
+        h_row = h_src[h_selem.long()]
+        return dict(Ph=Ph, Pa=Pa, B=B, h_src=h_src, h_selem=h_selem, h_row=h_row, h_inv=h_inv, h_seg=h_seg, a_selem=a_selem,
                     a_inv=a_inv, a_seg=a_seg, a_sel_l=a_sel_l, t_sel_l=t_sel_l, per_anchor=per_anchor,
-                    vox=_decode_xyz(matched_keys), ac_p2v=ac_first[a_sel_l], tr_p2v=tr_first[t_sel_l],
-                    row_anchor=(matched_keys >> 48),
+                    vox=_decode_xyz(matched_keys, cb), ac_p2v=ac_first[a_sel_l], tr_p2v=tr_first[t_sel_l],
+                    row_anchor=(matched_keys >> (3 * cb)),
                     h_start_d=d(h_start, torch.int64), frame_seg_d=d(frame_seg, torch.int32), seg_out_d=seg_out_d)
 
     def forward(self, anchor_batch: Dict, anchor_type: str, hist_batch: Dict, hist_type: str, geo: Dict = None) -> Dict:
@@ -200,8 +209,8 @@ class HR_Block(nn.Module):
 
         # ---- per-voxel means
         h_probs, h_ety = ops.softmax_entropy(h_logits.detach().float().contiguous())
-        tr_voxel_probs = ops.segment_reduce(h_probs, h_selem, h_seg, "mean", src_index=h_src)
-        tr_voxel_ety = ops.segment_reduce(h_ety, h_selem, h_seg, "mean", src_index=h_src)
+        tr_voxel_probs = ops.segment_reduce(h_probs, geo["h_row"], h_seg, "mean")
+        tr_voxel_ety = ops.segment_reduce(h_ety, geo["h_row"], h_seg, "mean")
         a_in = a_logits if a_logits.dtype == torch.float32 else a_logits.float()
         ac_voxel_probs = _VoxelMeanSoftmax.apply(a_in.contiguous(), geo["a_selem"], geo["a_inv"], geo["a_seg"])
 

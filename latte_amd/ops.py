@@ -416,20 +416,31 @@ def softmax_bwd(probs, gprobs):
     return out
 
 
-def st_keys(points, seg_out_start, seg_src_start, seg_anchor, seg_T, E: int, max_range, voxel_size, min_offset):
+def st_coord_bits(max_range, voxel_size) -> int:
+    """bits per ST-voxel coordinate: shifted coordinates lie in [0, 2*ceil(R/vs) + 1] (hr_module.py:53,62)"""
+    import math
+    return max(1, int(math.ceil(2.0 * max_range / voxel_size + 4.0)).bit_length())
+
+
+def st_keys(points, seg_out_start, seg_src_start, seg_anchor, seg_T, E: int, max_range, voxel_size, min_offset,
+            coord_bits: int | None = None):
+    """-> (keys int64 [E] = anchor << 3b | x << 2b | y << b | z with b = coord_bits, or INT64_MAX; src int32 [E])"""
     points = _chk(points, torch.float32, "st_keys points")
     S = seg_anchor.numel()
+    if coord_bits is None:
+        coord_bits = st_coord_bits(max_range, voxel_size)
     keys = torch.empty(E, dtype=torch.int64, device=points.device)
     src = torch.empty(E, dtype=torch.int32, device=points.device)
     _lib.call("lt_st_keys", _p(points), _p(_chk(seg_out_start, torch.int64, "seg_out_start")),
               _p(_chk(seg_src_start, torch.int64, "seg_src_start")), _p(_chk(seg_anchor, torch.int32, "seg_anchor")),
               _p(None if seg_T is None else _chk(seg_T, torch.float64, "seg_T")), S, int(E), float(max_range),
-              float(voxel_size), int(min_offset), _p(keys), _p(src), _stream())
+              float(voxel_size), int(min_offset), int(coord_bits), _p(keys), _p(src), _stream())
     return keys, src
 
 
-def sort_segments(keys: torch.Tensor):
-    """-> (sorted_elem int32 [E], inverse int32 [E], uniq_keys int64 [V], seg_start int32 [V+1])."""
+def sort_segments(keys: torch.Tensor, key_bits: int = 63):
+    """-> (sorted_elem int32 [E], inverse int32 [E], uniq_keys int64 [V], seg_start int32 [V+1]).  key_bits: every
+    unmasked key is < 2^key_bits (fewer radix passes)."""
     keys = _chk(keys.reshape(-1), torch.int64, "sort_segments keys")
     E = keys.numel()
     dev = keys.device
@@ -440,7 +451,7 @@ def sort_segments(keys: torch.Tensor):
     uk = torch.empty(max(E, 1), dtype=torch.int64, device=dev)
     seg = torch.zeros(E + 1, dtype=torch.int32, device=dev)
     v = ctypes.c_int64(0)
-    _lib.call("lt_sort_segments", _p(keys), E, 63, _p(ws), ws.numel(), _p(selem), _p(inv), _p(uk), _p(seg),
+    _lib.call("lt_sort_segments", _p(keys), E, int(key_bits), _p(ws), ws.numel(), _p(selem), _p(inv), _p(uk), _p(seg),
               ctypes.byref(v), _stream())
     V = v.value
     return selem, inv, uk[:V], seg[:V + 1]

@@ -24,7 +24,8 @@ def main():
     ap.add_argument("--stride", type=int, default=1, help="tensor stride of the level the conv runs on (1,2,4,8,16)")
     ap.add_argument("--order", default="auto", help="row processing order: auto (library default) | none | mask | morton")
     ap.add_argument("--reps", type=int, default=10)
-    ap.add_argument("--full360", action="store_true", default=True)
+    ap.add_argument("--beams", type=int, default=32)
+    ap.add_argument("--front", action="store_true", help="front-only +-45 degree scans (KITTI / A2D2 like) instead of 360 degrees")
     ap.add_argument("--out", default=None)
     ap.add_argument("--variant", type=int, default=0, help="lt_spconv_plan_fwd_v variant (with --order plan)")
     ap.add_argument("--variants", default=None, help="comma list of variants to sweep (with --order plan); each is checked "
@@ -44,7 +45,7 @@ def main():
     ops.CONV_VARIANT = args.variant
     coords = []
     for b in range(args.scans):
-        p, i = synth.make_scan(args.points, b, beams=32, full_360=True)
+        p, i = synth.make_scan(args.points, b, beams=args.beams, full_360=not args.front)
         c, f, _, _ = quantize_scan_gpu(torch.from_numpy(p).to(dev), torch.from_numpy(i).to(dev))
         coords.append(torch.cat([c, torch.full((c.shape[0], 1), b, dtype=torch.int32, device=dev)], 1))
     C4 = torch.cat(coords, 0)

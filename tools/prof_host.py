@@ -13,15 +13,17 @@ torch.manual_seed(1)
 model = Net3DSeg(w["C"], True, "SPVCNN", {"cr": 1.0}).cuda()
 step = LatteStep(model, w["C"], hr_cfg_of(w))
 batch = build_batch(w, device="cuda")
+PRE = len(sys.argv) > 2 and sys.argv[2] == "prefetch"   # main thread only: the helper thread's work is not profiled
 for _ in range(3):
-    step.step(batch)
+    step.step(batch, next_batch=batch if PRE else None)
 torch.cuda.synchronize()
 pr = cProfile.Profile()
 pr.enable()
 for _ in range(5):
-    step.step(batch)
+    step.step(batch, next_batch=batch if PRE else None)
 torch.cuda.synchronize()
 pr.disable()
+step.close()
 st = pstats.Stats(pr)
 st.sort_stats("cumulative").print_stats(60)
 st.sort_stats("tottime").print_stats(45)
