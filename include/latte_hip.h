@@ -199,6 +199,15 @@ int lt_conv_bn_bwd(const float* dy, const float* conv_out, const float* y, const
                    float* dgamma, float* dbeta, float* dres, float* dconv, const float* packed_bwd, const void* plan_bwd,
                    int64_t Vin, int32_t Cin, int32_t K, float* din, lt_stream_t stream);
 
+/* ------------------------------------------------------------------ parameter update
+ * torch.optim.Adam.step() over the norm parameters + update_ema_norm (latte/tta/tools/latte.py:317-323,
+ * latte/common/solver/build.py:7-52, latte/common/utils/ema_util.py:99-118) on FLAT fp32 buffers of n scalars, one
+ * launch: grad is scaled by grad_scale first (1/world after a sum all-reduce), Adam with L2 weight_decay and torch's
+ * bias corrections for `step` (counted from 1), then ema = ema_alpha*ema + (1-ema_alpha)*param (ema may be NULL). */
+int lt_adam_ema_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* ema, int64_t n, float lr,
+                     float beta1, float beta2, float eps, float weight_decay, int64_t step, float ema_alpha,
+                     float grad_scale, lt_stream_t stream);
+
 /* ------------------------------------------------------------------ point <-> voxel
  * F.spvoxelize(feats, idx, counts)  (torchsparse_utils.py:20,23,54): out[idx[i]] += f[i]/counts[idx[i]] */
 int lt_voxelize_fwd(const float* feats, const int32_t* idx, const int32_t* counts, float* out, int64_t N,

@@ -605,3 +605,17 @@ def conv_bn_bwd(dy, conv_out, y, mean, var, gamma, eps: float, relu: bool, need_
               cout, _p(ws), ws.numel(), _p(dgamma), _p(dbeta), _p(dres), _p(dconv), _p(packed_bwd), _p(plan_bwd),
               Vin, cin, K, _p(din), _stream())
     return din, dgamma, dbeta, dres
+
+
+# ------------------------------------------------------------------ parameter update
+def adam_ema_step(param, grad, exp_avg, exp_avg_sq, ema, lr: float, beta1: float, beta2: float, eps: float,
+                  weight_decay: float, step: int, ema_alpha: float, grad_scale: float = 1.0) -> None:
+    """In place over flat fp32 buffers: torch.optim.Adam's step, then ema = alpha*ema + (1-alpha)*param (lt_adam_ema_step)."""
+    n = param.numel()
+    for name, t in (("param", param), ("grad", grad), ("exp_avg", exp_avg), ("exp_avg_sq", exp_avg_sq), ("ema", ema)):
+        if t is None:
+            continue
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n):
+            raise ValueError(f"adam_ema_step: {name} must be a contiguous fp32 GPU buffer of {n} elements")
+    _lib.call("lt_adam_ema_step", _p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), _p(ema), n, float(lr), float(beta1),
+              float(beta2), float(eps), float(weight_decay), int(step), float(ema_alpha), float(grad_scale), _stream())

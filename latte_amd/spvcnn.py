@@ -18,7 +18,19 @@ __all__ = ["SPVCNN", "Net3DSeg", "BasicConvolutionBlock", "BasicDeconvolutionBlo
            "inverse_to_all"]
 
 
+# tests only: when a dict, every conv -> BN (+residual) (+ReLU) chain and every point-branch BN + ReLU stores its output
+# under id(BatchNorm module) (tests/test_gpu_spvcnn.py reads the ReLU activity pattern of a forward from it)
+ACT_TRACE = None
+
+
 def _conv_bn(seq, x: SparseTensor, i: int, relu: bool, residual=None) -> SparseTensor:
+    y = _conv_bn_impl(seq, x, i, relu, residual)
+    if ACT_TRACE is not None:
+        ACT_TRACE[id(seq[i + 1])] = y.feats.detach()
+    return y
+
+
+def _conv_bn_impl(seq, x: SparseTensor, i: int, relu: bool, residual=None) -> SparseTensor:
     """seq[i] = Conv3d, seq[i+1] = BatchNorm.  Hot case (frozen kernel, batch statistics, Cin % 16 == 0, on the GPU): one
     composite call -- conv with the BN statistics in its epilogue, finalize, BN(+residual)(+ReLU).  Otherwise conv, then
     the fused BN(+residual)(+ReLU) kernel."""
@@ -132,6 +144,10 @@ class SPVCNN(nn.Module):
         seq = self.point_transforms[i]
         if not f.is_cuda:
             return add_to + seq(f)
+        if ACT_TRACE is not None:
+            t = seq[1].bn_feats(seq[0](f), relu=True)
+            ACT_TRACE[id(seq[1])] = t.detach()
+            return add_to + t
         return seq[1].bn_feats(seq[0](f), residual=add_to, relu=True, post_add=True)
 
     def _up(self, up, y, skip):

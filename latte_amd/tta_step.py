@@ -24,7 +24,7 @@ from .hr_module import CR_Block, HR_Block
 from .spvcnn import inverse_to_all
 
 __all__ = ["configure_model_norm", "create_ema_model", "update_ema_norm", "refine_pseudo_labels", "pc2img_logit",
-           "LatteStep", "shard_scan_offset", "shard_sequences", "allreduce_mean_grads"]
+           "LatteStep", "FlatAdamEMA", "shard_scan_offset", "shard_sequences", "allreduce_mean_grads"]
 
 
 def configure_model_norm(model: nn.Module, reset_dropout: bool = True):
@@ -123,6 +123,67 @@ def allreduce_mean_grads(params: List[torch.Tensor], world: int, group=None) -> 
         off += n
 
 
+class FlatAdamEMA:
+    """torch.optim.Adam over the norm parameters + update_ema_norm as ONE launch over flat buffers
+    (latte/tta/tools/latte.py:317-323, latte/common/utils/ema_util.py:99-118).
+
+    The student's trainable parameters and the teacher's counterparts are re-pointed at views of two flat fp32 buffers
+    (13 248 scalars at cr = 1), gradients are gathered into a third with one multi-tensor copy -- which is also the
+    buffer the RCCL all-reduce runs on -- and lt_adam_ema_step does Adam + EMA in one kernel.  Same hyper-parameter
+    names and defaults as torch.optim.Adam (amsgrad / maximize are not supported)."""
+
+    def __init__(self, params, ema_params=None, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, ema_alpha=0.99):
+        self.params = list(params)
+        if not self.params:
+            raise ValueError("FlatAdamEMA: no parameters")
+        self.lr, self.betas, self.eps, self.weight_decay, self.ema_alpha = lr, tuple(betas), eps, weight_decay, ema_alpha
+        self.flat_p, _ = self._flatten(self.params)
+        self.flat_e = None
+        if ema_params is not None:
+            ema_params = list(ema_params)
+            if [tuple(p.shape) for p in ema_params] != [tuple(p.shape) for p in self.params]:
+                raise ValueError("FlatAdamEMA: teacher and student parameter lists differ")
+            self.flat_e, _ = self._flatten(ema_params)
+        self.flat_g = torch.zeros_like(self.flat_p)
+        self.g_views, off = [], 0
+        for p in self.params:
+            self.g_views.append(self.flat_g[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        self.exp_avg = torch.zeros_like(self.flat_p)
+        self.exp_avg_sq = torch.zeros_like(self.flat_p)
+        self.steps = 0
+
+    @staticmethod
+    def _flatten(params):
+        if not all(p.is_cuda and p.dtype == torch.float32 for p in params):
+            raise ValueError("FlatAdamEMA: fp32 GPU parameters only (move the model to the GPU first)")
+        flat = torch.cat([p.detach().reshape(-1) for p in params]).contiguous()
+        off = 0
+        for p in params:
+            p.data = flat[off:off + p.numel()].view_as(p)   # the parameter now aliases its slice of the flat buffer
+            off += p.numel()
+        return flat, off
+
+    def zero_grad(self, set_to_none: bool = True) -> None:
+        for p in self.params:
+            p.grad = None
+
+    def gather_grads(self) -> torch.Tensor:
+        """p.grad of every parameter -> the flat gradient buffer (one multi-tensor copy)"""
+        grads = [p.grad for p in self.params]
+        if any(g is None for g in grads):
+            missing = [i for i, g in enumerate(grads) if g is None]
+            raise RuntimeError(f"FlatAdamEMA: parameters {missing[:4]}... have no gradient; every norm layer of SPVCNN is on "
+                               "the path of the TTA losses, so this is a broken graph")
+        torch._foreach_copy_(self.g_views, grads)
+        return self.flat_g
+
+    def step(self, grad_scale: float = 1.0) -> None:
+        self.steps += 1
+        ops.adam_ema_step(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.flat_e, self.lr, self.betas[0],
+                          self.betas[1], self.eps, self.weight_decay, self.steps, self.ema_alpha, grad_scale)
+
+
 def shard_scan_offset(rank: int, scans_per_rank: int) -> int:
     """first global scan id of a rank: ranks own whole, disjoint sequences (no halo, no data-path collective)"""
     return rank * scans_per_rank
@@ -167,14 +228,21 @@ _KEEP_CACHE = bool(__import__("os").environ.get("LATTE_DIAG_KEEP_INDEX_CACHE"))
 class LatteStep:
     def __init__(self, model_3d: nn.Module, num_classes: int, hr_cfg: Dict, lr: float = 1e-3, conf_perc=None,
                  lambda_hr_23: float = 0.3, lambda_hr_32: float = 0.3, lambda_ety_ps: float = 1.0, class_weights=None,
-                 process_group=None, side_stream: bool = True):
+                 process_group=None, side_stream: bool = True, fused_optimizer: bool = True):
         self.model = configure_model_norm(model_3d, reset_dropout=True)
         self.ema_model = create_ema_model(self.model)
         self.hr = HR_Block(**hr_cfg)
         self.cr = CR_Block(reduction="mean", conf_mask=True, ety_weight=True)
-        self.params = [p for p in self.model.parameters() if p.requires_grad]
-        self.optimizer = torch.optim.Adam(self.params, lr=lr)
-        self._ema_pairs = (_norm_params(self.ema_model), _norm_params(self.model))
+        self.params = _norm_params(self.model)
+        assert {id(p) for p in self.params} == {id(p) for p in self.model.parameters() if p.requires_grad}
+        self._ema_pairs = (_norm_params(self.ema_model), self.params)
+        # fused_optimizer (default on the GPU): Adam + EMA as one launch over flat buffers; off: torch.optim.Adam and two
+        # multi-tensor EMA ops (the A/B and the parity reference of tests/test_gpu_step.py)
+        self.fused = bool(fused_optimizer) and self.params[0].is_cuda
+        if self.fused:
+            self.optimizer = FlatAdamEMA(self.params, self._ema_pairs[0], lr=lr, ema_alpha=0.99)
+        else:
+            self.optimizer = torch.optim.Adam(self.params, lr=lr)
         self.conf_perc = hr_cfg.get("conf_perc") if conf_perc is None else conf_perc
         self.lam23, self.lam32, self.lam_ps = lambda_hr_23, lambda_hr_32, lambda_ety_ps
         self.class_weights = class_weights
@@ -407,6 +475,25 @@ class LatteStep:
     def allreduce_grads(self):
         allreduce_mean_grads(self.params, self.world, self.pg)
 
+    def _update(self) -> None:
+        """all-reduce (N > 1), optimizer step, EMA teacher update (latte.py:317-323)"""
+        if not self.fused:
+            self.allreduce_grads()
+            self.optimizer.step()
+            update_ema_norm(self.ema_model, self.model, 0.99, self._ema_pairs)
+            return
+        flat = self.optimizer.gather_grads()
+        if self.world > 1:
+            # the only collective of the path: ONE all-reduce (RCCL over xGMI) of the flat gradient buffer; the mean is
+            # folded into the update kernel (grad_scale)
+            if flat.is_cuda and torch.distributed.get_backend(self.pg) == "gloo":
+                host = flat.cpu()
+                torch.distributed.all_reduce(host, group=self.pg)
+                flat.copy_(host)
+            else:
+                torch.distributed.all_reduce(flat, group=self.pg)
+        self.optimizer.step(grad_scale=1.0 / self.world)
+
     def step(self, batch: Dict, next_batch: Dict | None = None):
         """One TTA iteration on `batch`.  next_batch (optional): the batch of the NEXT iteration -- a helper thread starts
         building its input-only structures on the side stream right away (prefetch), beside this iteration."""
@@ -420,9 +507,7 @@ class LatteStep:
             self.prefetch(next_batch)
         self.optimizer.zero_grad(set_to_none=True)
         losses = self.forward_backward(batch, pre)
-        self.allreduce_grads()
-        self.optimizer.step()
-        update_ema_norm(self.ema_model, self.model, 0.99, self._ema_pairs)
+        self._update()
         self._tick("optim_ema")
         return losses
 

@@ -153,6 +153,7 @@ def hr_forward(anchor_batch, anchor_type, hist_batch, hist_type, temp_wd_size, m
         mask = torch.ones(torch.cat(out["tr_voxels"], 0).shape[0], dtype=torch.bool)
     out["tr_conf_mask"] = mask
     out["hs_pc_ety"] = hs_pc_ety
+    out["_voxel_ety_all"] = torch.cat(voxel_ety_all, 0).detach()   # not a key of the reference: what refine_ety saw (tests)
     return out
 
 

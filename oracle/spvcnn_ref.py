@@ -64,7 +64,18 @@ class SPVCNNRef:
         self.head = {k: v.detach().clone().to(dtype).cpu() for k, v in state_dict.items() if not k.startswith(prefix)}
         self.traced = {}
         self.acts = {}  # post BN(+residual)(+ReLU) activations by BatchNorm module name (debug / tests)
+        self.pre = {}   # the ReLU inputs under the same names (detached; the gradient-parity test looks at sign flips)
+        # optional {BatchNorm module name: bool tensor}: the ReLU under that name becomes x * mask (activity pattern given
+        # from outside: tests/test_gpu_spvcnn.py feeds the GPU run's pattern so that both backward passes take the same
+        # branch at activations that are zero to fp32 rounding)
+        self.relu_masks = None
         self.dtype = dtype
+
+    def _relu(self, x, name):
+        self.pre[name] = x.detach()
+        if self.relu_masks is not None:
+            return x * self.relu_masks[name].to(x.dtype)
+        return torch.relu(x)
 
     def parameters_requiring_grad(self, names):
         for n in names:
@@ -76,7 +87,7 @@ class SPVCNNRef:
         y = _conv(x, self.p[f"{pre}.{i}.kernel"], ks, stride, transposed)
         y.F = _bn(y.F, self.p[f"{pre}.{i + 1}.weight"], self.p[f"{pre}.{i + 1}.bias"])
         if relu:
-            y.F = torch.relu(y.F)
+            y.F = self._relu(y.F, f"{pre}.{i + 1}")
         self.acts[f"{pre}.{i + 1}"] = y.F
         return y
 
@@ -87,7 +98,7 @@ class SPVCNNRef:
             sc = self._cbr(x, f"{pre}.downsample", 0, 1, relu=False).F
         else:
             sc = x.F
-        y.F = torch.relu(y.F + sc)
+        y.F = self._relu(y.F + sc, f"{pre}.net.4")
         self.acts[f"{pre}.net.4"] = y.F
         return y
 
@@ -105,7 +116,7 @@ class SPVCNNRef:
     def _pt(self, f, i):
         pre = f"point_transforms.{i}"
         y = F.linear(f, self.p[f"{pre}.0.weight"], self.p[f"{pre}.0.bias"])
-        return torch.relu(_bn(y, self.p[f"{pre}.1.weight"], self.p[f"{pre}.1.bias"]))
+        return self._relu(_bn(y, self.p[f"{pre}.1.weight"], self.p[f"{pre}.1.bias"]), f"{pre}.1")
 
     # --- point <-> voxel (torchsparse_utils.py) -------------------------------------------------
     def _initial_voxelize(self, z: _PT, init_res, after_res):

@@ -53,10 +53,12 @@ def test_spvcnn_forward_matches_oracle(scans_small, cr):
     assert np.array_equal(t0.C.cpu().numpy(), x0)
     assert np.array_equal(z.additional_features["idx_query"][1].cpu().numpy(), ref.traced["idx_query_1"])
     t = t0
-    for lvl, name in zip((1, 2, 4, 8), ("x1", "x2", "x3", "x4")):
+    for lvl, name in zip((1, 2, 4, 8, 16), ("x1", "x2", "x3", "x4", None)):
         km3, _ = spnn.build_kernel_map(t, 3, 1, 1)
         nb, ns, sizes, _oc = ref.traced["kmaps"][(lvl, 3, 1)]
         assert np.array_equal(km3[0].cpu().numpy(), nb) and np.array_equal(km3[1].cpu().numpy(), ns)
+        if name is None:      # stride 16: the coarsest level has a 3^3 map only
+            break
         km2, oc = spnn.build_kernel_map(t, 2, 2, 1)
         nb, ns, sizes, want_oc = ref.traced["kmaps"][(lvl, 2, 2)]
         assert np.array_equal(oc.cpu().numpy(), want_oc) and np.array_equal(oc.cpu().numpy(), ref.traced[name + "_coords"])
@@ -125,3 +127,79 @@ def test_checkpoint_keys_follow_reference_names():
                      ("net_3d.point_transforms.0.0.weight", (256, 32)), ("net_3d.stem.1.running_mean", (32,)),
                      ("linear.weight", (9, 96)), ("linear2.bias", (9,))]:
         assert k in sd and tuple(sd[k].shape) == shape, k
+
+
+def test_spvcnn_bn_gradients_match_oracle_to_1e3_under_one_relu_pattern(scans_small):
+    """Whole-network gradient parity at the north_star bar (1e-3, median AND worst).
+
+    The forward passes agree to ~1e-6, which is enough to flip the sign of a handful of ReLU inputs that are zero to fp32
+    rounding; one flipped element changes every gradient below it by ~1/sqrt(rows*channels) of its norm, which is what
+    limits test_spvcnn_bn_gradients_match_oracle.  Here both facts are tested instead of told:
+      (1) the ReLU activity patterns of the two forwards differ only at such elements (|input| <= 1e-4 of the tensor's
+          scale, a vanishing fraction of all activations);
+      (2) with the oracle's backward taking the GPU forward's branch at every ReLU (oracle.relu_masks), every BatchNorm
+          gradient matches within 1e-3 relative -- what is left is kernel arithmetic."""
+    import latte_amd.spvcnn as spv
+    from latte_amd.tensor import SparseTensor
+    from oracle.spvcnn_ref import SPVCNNRef
+    m = make_model(0.5)
+    sd = m.state_dict()
+    names = [f"{mn}.{pn}"[len("net_3d."):] for mn, mod in m.named_modules() if isinstance(mod, torch.nn.BatchNorm1d)
+             for pn, _ in mod.named_parameters()]
+    coords, feats = scans_small["coords"], torch.from_numpy(scans_small["feats"])
+    g = torch.Generator().manual_seed(0)
+    tgt = torch.randint(0, 9, (coords.shape[0],), generator=g)
+
+    def loss_of(out, t):
+        return torch.nn.functional.cross_entropy(out["seg_logit"], t) + out["seg_logit2"].square().mean()
+
+    # GPU run, recording the output of every BN(+residual)+ReLU
+    mg = m.cuda()
+    mg.requires_grad_(False)
+    for mod in mg.modules():
+        if "norm" in type(mod).__name__.lower():
+            mod.requires_grad_(True)
+    lidar = SparseTensor(feats.cuda(), torch.from_numpy(coords).cuda(), 1)
+    spv.ACT_TRACE = {}
+    try:
+        got = mg({"lidar": lidar})
+    finally:
+        trace, spv.ACT_TRACE = spv.ACT_TRACE, None
+    loss = loss_of(got, tgt.cuda())
+    loss.backward()
+    name_of = {id(mod): mn[len("net_3d."):] for mn, mod in mg.named_modules() if mn.startswith("net_3d.")}
+    gpu_act = {name_of[k]: v.cpu() for k, v in trace.items()}
+
+    # (1) free-running oracle: where do the activity patterns differ?
+    ref = SPVCNNRef(sd)
+    with torch.no_grad():
+        ref(coords, feats)
+    relu_names = sorted(ref.pre.keys())
+    assert set(relu_names) <= set(gpu_act.keys()), set(relu_names) - set(gpu_act.keys())
+    total = flips = 0
+    for n in relu_names:
+        pre = ref.pre[n]
+        differ = (pre > 0) != (gpu_act[n] > 0)
+        total += pre.numel()
+        flips += int(differ.sum())
+        if differ.any():
+            assert float(pre[differ].abs().max()) <= 1e-4 * float(pre.abs().max()), n
+    assert flips <= 1e-5 * total, (flips, total)
+    print(f"ReLU inputs: {total}, sign flips between the oracle and the GPU forward: {flips}")
+
+    # (2) oracle backward under the GPU forward's activity pattern
+    ref = SPVCNNRef(sd)
+    ref.relu_masks = {n: gpu_act[n] > 0 for n in relu_names}
+    ref_params = ref.parameters_requiring_grad(names)
+    loss_ref = loss_of(ref(coords, feats), tgt)
+    loss_ref.backward()
+    assert abs(float(loss) - float(loss_ref)) < 1e-4 * abs(float(loss_ref))
+    params = dict(mg.named_parameters())
+    errs = []
+    for n, pr in zip(names, ref_params):
+        pg = params["net_3d." + n].grad.cpu().double()
+        errs.append((float((pg - pr.grad.double()).norm() / (pr.grad.double().norm() + 1e-12)), n))
+    errs.sort(reverse=True)
+    print("BN-grad rel errs under one ReLU pattern (worst 4):", errs[:4], "median", errs[len(errs) // 2][0])
+    assert errs[len(errs) // 2][0] < RTOL
+    assert errs[0][0] < RTOL, errs[0]

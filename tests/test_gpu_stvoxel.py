@@ -38,8 +38,19 @@ def test_hr_cr_block_matches_reference_golden(case, tag):
     assert np.allclose(d["hs_pc_ety"].cpu().numpy(), z[f"{tag}_hs_pc_ety"], rtol=RTOL, atol=1e-6)
     got_mask, want_mask = d["tr_conf_mask"].cpu().numpy(), z[f"{tag}_tr_conf_mask"]
     assert got_mask.shape == want_mask.shape
-    # an entropy equal to its class threshold within 1 ulp may fall on either side
-    assert (got_mask != want_mask).sum() <= 2
+    # an entropy equal to its class threshold to fp32 rounding may fall on either side: at most 2 such entries, and every
+    # one of them IS such a tie (entropy within 2 ulp of the class quantile the oracle computes from the same inputs)
+    bad = np.nonzero(got_mask != want_mask)[0]
+    assert bad.size <= 2
+    if bad.size:
+        o = hr_ref.hr_forward(dict(ab, seg_logit=a_lg.detach()), at, dict(hb, seg_logit=hb["seg_logit"].cpu()), ht,
+                              cfg["temp_wd_size"], cfg["max_range"], cfg["voxel_size"], cfg["conf_perc"])
+        lab = torch.cat(o["tr_logits"], 0).argmax(1)
+        ety = o["_voxel_ety_all"][:lab.numel()]
+        for i in bad:
+            assert i < lab.numel()
+            thr = float(torch.quantile(ety[lab == lab[i]], cfg["conf_perc"]))
+            assert abs(float(ety[i]) - thr) <= 2 * np.spacing(np.float32(thr)), (i, float(ety[i]), thr)
     d["ac_pc_ety"] = torch.from_numpy(z[f"{tag}_ac_pc_ety"]).cuda()
     d["tr_pc_ety"] = torch.from_numpy(z[f"{tag}_tr_pc_ety"]).cuda()
     if (got_mask != want_mask).any():
