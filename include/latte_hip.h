@@ -136,6 +136,16 @@ int64_t lt_spconv_stats_bytes(int64_t Vout, int32_t Cout);
 int lt_spconv_plan_fwd_stats(const float* in, const float* packed, const void* plan, float* out, int64_t Vin, int64_t Vout,
                              int32_t Cin, int32_t Cout, int32_t K, void* stats_ws, lt_stream_t stream);
 
+/* spnn.Conv3d backward-weight (torchsparse conv3d backward: grad_weight[k] = in[nbmaps_k[:,0]]^T @ gout[nbmaps_k[:,1]]; reached
+ * with TRAIN.UPDATE_PARAMS == "all": latte/common/utils/ema_util.py:44-71, latte/tta/tools/latte.py:324-326).
+ * nbmaps / nbsizes: the pair list of the kernel map (lt_kmap_pairs), M = its length; transposed != 0: the conv ran the map
+ * backwards (in rows = nbmaps[:,1], gout rows = nbmaps[:,0]).  dW [K,Cin,Cout] fp32.  Cin, Cout multiples of 16.  Pair
+ * slices are reduced in a fixed order: bitwise reproducible. */
+int64_t lt_spconv_bwd_weight_workspace_bytes(int64_t M, int32_t K, int32_t Cin, int32_t Cout);
+int lt_spconv_bwd_weight(const float* in, const float* gout, const int32_t* nbmaps, const int32_t* nbsizes, int64_t M,
+                         int64_t Vin, int64_t Vout, int32_t Cin, int32_t Cout, int32_t K, int32_t transposed, void* ws,
+                         int64_t ws_bytes, float* dW, lt_stream_t stream);
+
 /* Conv launch timer -- measurement aid, no counterpart in the reference (bench.py's roofline leg uses it).  Between
  * begin and end every sparse-conv kernel launch of this library (lt_spconv_fwd, lt_spconv_plan_fwd*, and the ones inside
  * lt_conv_bn_fwd/bwd) is bracketed by two hipEvents on the launch stream.  lt_conv_timer_end [sync] waits for them and

@@ -220,19 +220,23 @@ class _SparseConv(Function):
             else:
                 gfeats = _run_conv(gout, _packed(weight, 1, ctx.wcache), kmap, False, cin)
         if ctx.needs_input_grad[1]:
-            # dW is only reached when TRAIN.UPDATE_PARAMS == "all" (latte/common/utils/ema_util.py:44-71); the
-            # shipped Latte configs train norm layers only.  Device-side torch ops over the pair list (not HIP yet).
+            # dW is only reached when TRAIN.UPDATE_PARAMS == "all" (latte/common/utils/ema_util.py:44-71); the shipped
+            # Latte configs train norm layers only.  lt_spconv_bwd_weight over the pair list of the map.
             nbmaps, nbsizes = kmap.pairs()
-            sizes = nbsizes.tolist()
-            gw = torch.zeros_like(w)
-            off = 0
-            for k, m in enumerate(sizes):
-                if m == 0:
-                    continue
-                p = nbmaps[off:off + m].long()
-                off += m
-                i_in, i_out = (p[:, 1], p[:, 0]) if transposed else (p[:, 0], p[:, 1])
-                gw[k] = feats[i_in].t() @ gout[i_out]
+            if w.shape[1] % 16 == 0 and w.shape[2] % 16 == 0:
+                gw = ops.spconv_bwd_weight(feats, gout, nbmaps, nbsizes, w.shape[0], w.shape[1], w.shape[2], transposed)
+            else:
+                # the 4-channel stem (and other widths the MFMA tiling does not take): per-offset GEMMs in torch
+                sizes = nbsizes.tolist()
+                gw = torch.zeros_like(w)
+                off = 0
+                for k, m in enumerate(sizes):
+                    if m == 0:
+                        continue
+                    p = nbmaps[off:off + m].long()
+                    off += m
+                    i_in, i_out = (p[:, 1], p[:, 0]) if transposed else (p[:, 0], p[:, 1])
+                    gw[k] = feats[i_in].t() @ gout[i_out]
             gweight = gw if weight.dim() == 3 else gw[0]
         return gfeats, gweight, None, None, None
 

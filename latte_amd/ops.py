@@ -238,6 +238,22 @@ def spconv(feats: torch.Tensor, packed: torch.Tensor, nbr: torch.Tensor, cout: i
     return out
 
 
+def spconv_bwd_weight(feats, gout, nbmaps, nbsizes, K: int, cin: int, cout: int, transposed: bool = False):
+    """dW [K,Cin,Cout] = per offset feats[in rows]^T @ gout[out rows] over the pair list (lt_spconv_bwd_weight)."""
+    feats = _chk(feats, torch.float32, "bwd_weight feats")
+    gout = _chk(gout, torch.float32, "bwd_weight gout")
+    nbmaps = _chk(nbmaps, torch.int32, "bwd_weight nbmaps")
+    nbsizes = _chk(nbsizes, torch.int32, "bwd_weight nbsizes")
+    M = nbmaps.shape[0]
+    assert feats.shape[1] == cin and gout.shape[1] == cout and nbsizes.numel() == K
+    lib = _lib.load()
+    ws = _ws(lib.lt_spconv_bwd_weight_workspace_bytes(M, K, cin, cout), feats.device)
+    dW = torch.empty((K, cin, cout), dtype=torch.float32, device=feats.device)
+    _lib.call("lt_spconv_bwd_weight", _p(feats), _p(gout), _p(nbmaps), _p(nbsizes), M, feats.shape[0], gout.shape[0],
+              int(cin), int(cout), int(K), int(bool(transposed)), _p(ws), ws.numel(), _p(dW), _stream())
+    return dW
+
+
 CONV_VARIANT = 0  # lt_spconv_plan_fwd_v variant (0 = library default); tuning knob of tools/conv_bench.py
 
 
