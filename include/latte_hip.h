@@ -209,6 +209,15 @@ int lt_conv_bn_bwd(const float* dy, const float* conv_out, const float* y, const
                    float* dgamma, float* dbeta, float* dres, float* dconv, const float* packed_bwd, const void* plan_bwd,
                    int64_t Vin, int32_t Cin, int32_t K, float* din, lt_stream_t stream);
 
+/* ------------------------------------------------------------------ heads + inverse_to_all
+ * Net3DSeg's linear heads (latte/models/xmuda_arch.py:326-335) fused with inverse_to_all (latte/data/collate.py:34-55):
+ * out1[p,:] = feats[idx[p],:] @ E[:, 0:C1] + bias[0:C1], out2[p,:] = feats[idx[p],:] @ E[:, C1:C1+C2] + bias[C1:C1+C2]
+ * for the N raw points (idx int64 [N] into the V feature rows, NULL = identity; rows outside [0,V) read as zeros).
+ * packed = lt_spconv_pack_weights(E, K=1, Cin, 16*ceil((C1+C2)/16), mode 0) of E = [W1^T | W2^T | 0]; bias padded to the
+ * same width.  Cin % 16 == 0, Cin <= 128, C1 + C2 <= 64; C2 = 0: one head. */
+int lt_head_gather_fwd(const float* feats, const int64_t* idx, const float* packed, const float* bias, int64_t N, int64_t V,
+                       int32_t Cin, int32_t C1, int32_t C2, float* out1, float* out2, lt_stream_t stream);
+
 /* ------------------------------------------------------------------ parameter update
  * torch.optim.Adam.step() over the norm parameters + update_ema_norm (latte/tta/tools/latte.py:317-323,
  * latte/common/solver/build.py:7-52, latte/common/utils/ema_util.py:99-118) on FLAT fp32 buffers of n scalars, one

@@ -67,6 +67,7 @@ SIGNATURES = {
     "lt_bn_apply": (ctypes.c_int, [P, P, P, P, P, F32, P, I32, P, I64, I32, P]),
     "lt_bn_bwd_reduce": (ctypes.c_int, [P, P, P, P, P, P, P, F32, I32, I64, I32, P, I64, P, P, P]),
     "lt_bn_bwd_apply": (ctypes.c_int, [P, P, P, P, P, P, P, F32, I32, P, P, P, P, I64, I32, P]),
+    "lt_head_gather_fwd": (ctypes.c_int, [P, P, P, P, I64, I64, I32, I32, I32, P, P, P]),
     "lt_adam_ema_step": (ctypes.c_int, [P, P, P, P, P, I64, F32, F32, F32, F32, F32, I64, F32, F32, P]),
     "lt_voxelize_fwd": (ctypes.c_int, [P, P, P, P, I64, I32, I64, P]),
     "lt_voxelize_bwd": (ctypes.c_int, [P, P, P, P, I64, I32, I64, P]),

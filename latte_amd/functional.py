@@ -355,6 +355,61 @@ class _GatherRows(Function):
         return out, None
 
 
+class _HeadGather(Function):
+    """Both segmentation heads evaluated at the raw points: out_h = feats[idx] @ W_h^T + b_h (lt_head_gather_fwd).
+    Backward: the point gradients are summed per feature row over a CSR of idx (atomic-free, ascending point order:
+    lt_segment_reduce), the rest is two small dense products."""
+
+    @staticmethod
+    def forward(ctx, feats, w1, b1, w2, b2, idx, csr, packed, bias):
+        c1 = w1.shape[0]
+        c2 = w2.shape[0] if w2 is not None else 0
+        out1, out2 = ops.head_gather_fwd(feats, idx, packed, bias, c1, c2)
+        ctx.save_for_backward(feats, w1, w2, idx)
+        ctx.csr = csr
+        ctx.set_materialize_grads(False)   # a head the loss does not use (seg_logit2 in Latte) costs nothing in the backward
+        if out2 is None:
+            ctx.mark_non_differentiable()
+            return out1, feats.new_zeros(0)
+        return out1, out2
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        feats, w1, w2, idx = ctx.saved_tensors
+        V = feats.shape[0]
+        csr = ctx.csr() if callable(ctx.csr) else ctx.csr
+        if csr is None:
+            csr = ops.csr_build(idx.to(torch.int32), V)
+        perm, off = csr
+        gs1 = ops.segment_reduce(g1.contiguous(), perm, off, "sum") if g1 is not None else None    # [V, C1]
+        gs2 = ops.segment_reduce(g2.contiguous(), perm, off, "sum") if (g2 is not None and w2 is not None) else None
+        gfeats = gw1 = gb1 = gw2 = gb2 = None
+        if ctx.needs_input_grad[0]:
+            if gs1 is not None:
+                gfeats = gs1 @ w1
+            if gs2 is not None:
+                gfeats = gs2 @ w2 if gfeats is None else torch.addmm(gfeats, gs2, w2)
+            if gfeats is None:
+                gfeats = torch.zeros_like(feats)
+        if gs1 is not None:
+            if ctx.needs_input_grad[1]:
+                gw1 = gs1.t() @ feats
+            if ctx.needs_input_grad[2]:
+                gb1 = gs1.sum(0)
+        if gs2 is not None:
+            if ctx.needs_input_grad[3]:
+                gw2 = gs2.t() @ feats
+            if ctx.needs_input_grad[4]:
+                gb2 = gs2.sum(0)
+        return gfeats, gw1, gb1, gw2, gb2, None, None, None, None
+
+
+def head_gather(feats, w1, b1, w2, b2, idx, csr, packed, bias):
+    """-> (logits of head 1 [N,C], logits of head 2 [N,C] | None) at the rows feats[idx]; see _HeadGather."""
+    o1, o2 = _HeadGather.apply(feats.contiguous(), w1, b1, w2, b2, idx, csr, packed, bias)
+    return o1, (o2 if w2 is not None else None)
+
+
 def gather_rows(x: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     """x[idx] for an int64 row index vector, with a cheap backward."""
     if not (x.requires_grad and torch.is_grad_enabled()):

@@ -635,3 +635,20 @@ def adam_ema_step(param, grad, exp_avg, exp_avg_sq, ema, lr: float, beta1: float
             raise ValueError(f"adam_ema_step: {name} must be a contiguous fp32 GPU buffer of {n} elements")
     _lib.call("lt_adam_ema_step", _p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), _p(ema), n, float(lr), float(beta1),
               float(beta2), float(eps), float(weight_decay), int(step), float(ema_alpha), float(grad_scale), _stream())
+
+
+# ------------------------------------------------------------------ heads + inverse_to_all
+def head_gather_fwd(feats, idx, packed, bias, c1: int, c2: int):
+    """-> (out1 [N,c1], out2 [N,c2] | None): both linear heads at the rows feats[idx] (lt_head_gather_fwd)."""
+    feats = _chk(feats, torch.float32, "head feats")
+    V, Cin = feats.shape
+    if idx is not None:
+        idx = _chk(idx, torch.int64, "head idx")
+        N = idx.numel()
+    else:
+        N = V
+    out1 = torch.empty((N, c1), dtype=torch.float32, device=feats.device)
+    out2 = torch.empty((N, c2), dtype=torch.float32, device=feats.device) if c2 > 0 else None
+    _lib.call("lt_head_gather_fwd", _p(feats), _p(idx), _p(_chk(packed, torch.float32, "head packed")),
+              _p(_chk(bias, torch.float32, "head bias")), N, V, int(Cin), int(c1), int(c2), _p(out1), _p(out2), _stream())
+    return out1, out2

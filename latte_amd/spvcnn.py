@@ -251,6 +251,53 @@ class Net3DSeg(nn.Module):
             preds["seg_logit2"] = self.linear2(feats)
         return preds
 
+    def _packed_heads(self):
+        """MFMA-fragment image of E = [W1^T | W2^T | 0] and the padded bias, re-made when a head parameter changes (same
+        invalidation rules as the conv kernels: functional.PACK_EPOCH)."""
+        from . import functional as LF
+        from . import ops
+        heads = [self.linear] + ([self.linear2] if self.dual_head else [])
+        tag = tuple((h.weight._version, h.weight.data_ptr(), h.bias._version, h.bias.data_ptr()) for h in heads) + (LF.PACK_EPOCH,)
+        hit = getattr(self, "_head_cache", None)
+        if hit is not None and hit[0] == tag:
+            return hit[1], hit[2]
+        with torch.no_grad():
+            c = sum(h.weight.shape[0] for h in heads)
+            width = (c + 15) // 16 * 16
+            E = torch.zeros(self.net_3d.out_channels, width, device=self.linear.weight.device)
+            bias = torch.zeros(width, device=E.device)
+            o = 0
+            for h in heads:
+                n = h.weight.shape[0]
+                E[:, o:o + n] = h.weight.t()
+                bias[o:o + n] = h.bias
+                o += n
+            packed = ops.pack_weights(E.unsqueeze(0).contiguous(), 0)
+        self._head_cache = (tag, packed, bias)
+        return packed, bias
+
+    def forward_points(self, data_batch, inv_all: torch.Tensor, csr=None):
+        """forward() followed by inverse_to_all (latte/data/collate.py:34-55) on the logits, as one kernel: the heads are
+        evaluated at the raw points, out[p] = head(feats[inv_all[p]]) (lt_head_gather_fwd).  inv_all: int64 [N] row of
+        every raw point in the batch's unique-voxel numbering (LatteStep._batch_tables); csr (optional): ops.csr_build of
+        it, for the backward.  -> {'feats' [V,C'], 'seg_logit' [N,C], 'seg_logit2' [N,C]}"""
+        from . import functional as LF
+        feats = self.net_3d(data_batch["lidar"])
+        if (not feats.is_cuda or feats.shape[1] % 16 != 0 or feats.shape[1] > 128
+                or self.linear.weight.shape[0] * (2 if self.dual_head else 1) > 64):
+            out = {"feats": feats, "seg_logit": LF.gather_rows(self.linear(feats), inv_all)}
+            if self.dual_head:
+                out["seg_logit2"] = LF.gather_rows(self.linear2(feats), inv_all)
+            return out
+        packed, bias = self._packed_heads()
+        l2 = self.linear2 if self.dual_head else None
+        o1, o2 = LF.head_gather(feats, self.linear.weight, self.linear.bias, l2.weight if l2 is not None else None,
+                                l2.bias if l2 is not None else None, inv_all, csr, packed, bias)
+        out = {"feats": feats, "seg_logit": o1}
+        if self.dual_head:
+            out["seg_logit2"] = o2
+        return out
+
 
 def inverse_to_all(seg_logit: torch.Tensor, data_batch) -> torch.Tensor:
     """Unique-voxel rows -> all raw points (latte/data/collate.py:34-55): one gather with a batch-offset index

@@ -293,7 +293,11 @@ class LatteStep:
             iv = iv if torch.is_tensor(iv) else torch.as_tensor(iv)
             inv.append(iv.to(mask.device, dtype=torch.int64) + off)
             off += n
-        return {"mask": mask, "fov_idx": fov_idx, "ori_2d": ori_2d, "inv_all": torch.cat(inv, 0)}
+        inv_all = torch.cat(inv, 0)
+        # CSR of inv_all (raw points of every unique voxel, ascending): the heads' backward sums point gradients per voxel
+        # over it instead of an atomic index_add
+        inv_csr = ops.csr_build(inv_all.to(torch.int32), int(sum(sizes))) if inv_all.is_cuda else None
+        return {"mask": mask, "fov_idx": fov_idx, "ori_2d": ori_2d, "inv_all": inv_all, "inv_csr": inv_csr}
 
     def _side_stream(self):
         if not (self.hr_side_stream and self.timers is None):
@@ -421,8 +425,7 @@ class LatteStep:
         a2, h2, a3, h3 = self._hr_inputs(batch, tab)
 
         with torch.no_grad():
-            ema3d = self.ema_model(batch)
-            ema3d["seg_logit"] = ema3d["seg_logit"][tab["inv_all"]]     # inverse_to_all
+            ema3d = self.ema_model.forward_points(batch, tab["inv_all"])   # heads + inverse_to_all in one kernel
         self._tick("teacher_fwd")
         late_geo = side is not None and geo23 is None
         if late_geo:
@@ -430,8 +433,7 @@ class LatteStep:
             with torch.cuda.stream(side):
                 geo23 = self.hr.geometry(a2, "2D", h3, "3D")
                 geo32 = self.hr.geometry(a3, "3D", h2, "2D")
-        preds_3d = self.model(batch)
-        preds_3d["seg_logit"] = gather_rows(preds_3d["seg_logit"], tab["inv_all"])
+        preds_3d = self.model.forward_points(batch, tab["inv_all"], tab.get("inv_csr"))
         self._tick("student_fwd")
         if late_geo:
             main.wait_stream(side)

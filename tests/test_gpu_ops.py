@@ -610,3 +610,63 @@ def test_conv3d_module_trains_its_kernel_through_the_hip_backward(scans_small):
             after = conv(SparseTensor(feats.cuda(), coords, 1)).F
         assert not torch.allclose(before, after)          # the packed-weight cache followed the optimizer step
         del down
+
+
+@pytest.mark.parametrize("cin,c,dual", [(96, 10, True), (96, 16, True), (48, 9, True), (96, 5, False), (128, 32, True)])
+def test_head_gather_matches_linear_then_gather(cin, c, dual):
+    """lt_head_gather_fwd (heads evaluated at the raw points) against nn.Linear on the voxel rows followed by the
+    inverse_to_all gather (xmuda_arch.py:326-335, collate.py:34-55): forward 1e-5, gradients to the features and to the
+    head parameters 1e-5, out-of-range / ragged tail handled."""
+    from latte_amd import functional as LF
+    from latte_amd import ops
+    g = torch.Generator().manual_seed(cin + c)
+    V, N = 5003, 20011                                       # ragged: N % 16 != 0
+    feats = torch.randn(V, cin, generator=g)
+    idx = torch.randint(0, V, (N,), generator=g)
+    idx[:7] = V - 1
+    w1, b1 = torch.randn(c, cin, generator=g) / cin ** 0.5, torch.randn(c, generator=g)
+    w2, b2 = (torch.randn(c, cin, generator=g) / cin ** 0.5, torch.randn(c, generator=g)) if dual else (None, None)
+    gw1, gw2 = torch.randn(N, c, generator=g), torch.randn(N, c, generator=g)
+
+    def leaf(t):
+        return None if t is None else t.clone().requires_grad_(True)
+    f_r, w1_r, b1_r, w2_r, b2_r = leaf(feats), leaf(w1), leaf(b1), leaf(w2), leaf(b2)
+    want1 = torch.nn.functional.linear(f_r, w1_r, b1_r)[idx]
+    loss = (want1 * gw1).sum()
+    if dual:
+        want2 = torch.nn.functional.linear(f_r, w2_r, b2_r)[idx]
+        loss = loss + (want2 * gw2).sum()
+    loss.backward()
+
+    dev_ = lambda t: None if t is None else t.cuda().requires_grad_(True)
+    f_g, w1_g, b1_g, w2_g, b2_g = dev_(feats), dev_(w1), dev_(b1), dev_(w2), dev_(b2)
+    width = ((2 * c if dual else c) + 15) // 16 * 16
+    E = torch.zeros(cin, width)
+    bias = torch.zeros(width)
+    E[:, :c], bias[:c] = w1.t(), b1
+    if dual:
+        E[:, c:2 * c], bias[c:2 * c] = w2.t(), b2
+    packed = ops.pack_weights(E.unsqueeze(0).cuda(), 0)
+    idx_g = idx.cuda()
+    csr = ops.csr_build(idx_g.int(), V)
+    o1, o2 = LF.head_gather(f_g, w1_g, b1_g, w2_g, b2_g, idx_g, csr, packed, bias.cuda())
+    assert rel_err(o1.detach().cpu(), want1.detach()) < 1e-5
+    l = (o1 * gw1.cuda()).sum()
+    if dual:
+        assert rel_err(o2.detach().cpu(), want2.detach()) < 1e-5
+        l = l + (o2 * gw2.cuda()).sum()
+    else:
+        assert o2 is None
+    l.backward()
+    for got, want in ((f_g, f_r), (w1_g, w1_r), (b1_g, b1_r)) + (((w2_g, w2_r), (b2_g, b2_r)) if dual else ()):
+        assert rel_err(got.grad.cpu(), want.grad) < 1e-5
+    # identity index (idx = None) and a head the loss ignores
+    o1n, _ = ops.head_gather_fwd(feats.cuda(), None, packed, bias.cuda(), c, c if dual else 0)
+    assert rel_err(o1n.cpu(), torch.nn.functional.linear(feats, w1, b1)) < 1e-5
+    if dual:
+        f2 = feats.cuda().requires_grad_(True)
+        a1, _a2 = LF.head_gather(f2, w1.cuda(), b1.cuda(), w2.cuda(), b2.cuda(), idx_g, None, packed, bias.cuda())
+        (a1 * gw1.cuda()).sum().backward()
+        f3 = feats.clone().requires_grad_(True)
+        (torch.nn.functional.linear(f3, w1, b1)[idx] * gw1).sum().backward()
+        assert rel_err(f2.grad.cpu(), f3.grad) < 1e-5
