@@ -136,6 +136,10 @@ int64_t lt_spconv_stats_bytes(int64_t Vout, int32_t Cout);
 int lt_spconv_plan_fwd_stats(const float* in, const float* packed, const void* plan, float* out, int64_t Vin, int64_t Vout,
                              int32_t Cin, int32_t Cout, int32_t K, void* stats_ws, lt_stream_t stream);
 
+/* The network's first conv (latte/models/spvcnn.py:29-31: spnn.Conv3d(4, cs[0], 3)): 4 input channels -> 16 | 32, a
+ * streaming kernel (one lane per output row) over a plan of the table; weight is the UNPACKED kernel [K, 4, Cout]. */
+int lt_spconv_stem_fwd(const float* in, const float* weight, const void* plan, float* out, int64_t Vin, int64_t Vout,
+                       int32_t Cin, int32_t Cout, int32_t K, lt_stream_t stream);
 /* spnn.Conv3d backward-weight (torchsparse conv3d backward: grad_weight[k] = in[nbmaps_k[:,0]]^T @ gout[nbmaps_k[:,1]]; reached
  * with TRAIN.UPDATE_PARAMS == "all": latte/common/utils/ema_util.py:44-71, latte/tta/tools/latte.py:324-326).
  * nbmaps / nbsizes: the pair list of the kernel map (lt_kmap_pairs), M = its length; transposed != 0: the conv ran the map

@@ -59,6 +59,7 @@ SIGNATURES = {
     "lt_spconv_packed_floats": (I64, [I32, I32, I32]),
     "lt_spconv_pack_weights": (ctypes.c_int, [P, I32, I32, I32, I32, P, P]),
     "lt_spconv_fwd": (ctypes.c_int, [P, P, P, P, P, I64, I64, I32, I32, I32, P]),
+    "lt_spconv_stem_fwd": (ctypes.c_int, [P, P, P, P, I64, I64, I32, I32, I32, P]),
     "lt_spconv_bwd_weight_workspace_bytes": (I64, [I64, I32, I32, I32]),
     "lt_spconv_bwd_weight": (ctypes.c_int, [P, P, P, P, I64, I64, I64, I32, I32, I32, I32, P, I64, P, P]),
     "lt_bn_workspace_bytes": (I64, [I64, I32]),

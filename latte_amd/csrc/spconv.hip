@@ -1387,6 +1387,63 @@ extern "C" int lt_spconv_plan_fwd(const float* in, const float* packed, const vo
   return lt_spconv_plan_fwd_v(in, packed, plan, out, Vin, Vout, Cin, Cout, K, 0, stream);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Stem kernel: Cin = 4 (the network's input: x, y, z, intensity -> 32 channels, latte/models/spvcnn.py:29-31).  With four
+// input channels the conv is a streaming problem (per output row: 27 table entries, ~6.5 gathered 16-B rows, 128 B out),
+// not a matrix one -- an MFMA tile would be 4/16 full.  One lane per output row, one wave per 64-row plan tile: the tile's
+// neighbour rows come coalesced from the plan (tnbr), offsets without a neighbour in the tile are skipped from the tile's
+// row masks (rows are mask-sorted: ~7 of 27 offsets survive), the weights of an offset are wave-uniform and come through
+// scalar loads (no LDS, no vector loads), COUT accumulators per lane.
+template <int COUT>
+__global__ __launch_bounds__(256) void k_spconv_stem(PlanArgs a, const float* __restrict__ W) {
+  const int lane = threadIdx.x & 63;
+  const int64_t T = ((int64_t)a.Vout + LT_TM - 1) / LT_TM;
+  const int64_t tile = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform
+  if (tile >= T) return;
+  const int64_t slot = tile * LT_TM + lane;
+  const int row = slot < a.Vout ? a.order[slot] : -1;
+  float acc[COUT];
+#pragma unroll
+  for (int c = 0; c < COUT; ++c) acc[c] = 0.f;
+  for (int k = 0; k < a.K; ++k) {
+    const unsigned long long m = a.tmask[tile * a.K + k];   // wave-uniform
+    if (m == 0ull) continue;
+    const int nb = a.tnbr[(tile * a.K + k) * LT_TM + lane];
+    f32x4 x = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (nb >= 0 && nb < a.Vin) x = *reinterpret_cast<const f32x4*>(a.in + (int64_t)nb * 4);
+    const float* wk = W + (int64_t)k * 4 * COUT;             // [4][COUT], uniform address: scalar loads
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+      for (int c = 0; c < COUT; ++c) acc[c] = __builtin_fmaf(x[ci], wk[ci * COUT + c], acc[c]);
+  }
+  if (row >= 0) {
+    f32x4* o = reinterpret_cast<f32x4*>(a.out + (int64_t)row * COUT);
+#pragma unroll
+    for (int c = 0; c < COUT / 4; ++c) o[c] = (f32x4){acc[4 * c], acc[4 * c + 1], acc[4 * c + 2], acc[4 * c + 3]};
+  }
+}
+
+extern "C" int lt_spconv_stem_fwd(const float* in, const float* weight, const void* plan, float* out, int64_t Vin,
+                                  int64_t Vout, int32_t Cin, int32_t Cout, int32_t K, hipStream_t stream) {
+  LT_REQUIRE(Vin >= 0 && Vout >= 0 && Vin < INT32_MAX && Vout < INT32_MAX, LT_ERR_RANGE, "lt_spconv_stem_fwd: bad row counts");
+  LT_REQUIRE(K >= 1 && K <= LT_KMAX, LT_ERR_ARG, "lt_spconv_stem_fwd: kernel volume %d not in [1,%d]", K, LT_KMAX);
+  LT_REQUIRE(Cin == 4 && (Cout == 16 || Cout == 32), LT_ERR_ARG,
+             "lt_spconv_stem_fwd: Cin=%d, Cout=%d (the stem kernel takes 4 input channels and 16 or 32 outputs)", Cin, Cout);
+  if (Vout == 0) return LT_OK;
+  LT_REQUIRE(weight && plan && out && (Vin == 0 || in), LT_ERR_ARG, "lt_spconv_stem_fwd: null pointer");
+  LT_REQUIRE(((uintptr_t)plan & 15) == 0 && ((uintptr_t)in & 15) == 0 && ((uintptr_t)out & 15) == 0, LT_ERR_ARG,
+             "lt_spconv_stem_fwd: plan, in and out must be 16-byte aligned");
+  LtPlanView pv = lt_plan_view(const_cast<void*>(plan), K, Vout);
+  PlanArgs a{in, nullptr, pv.tnbr, pv.tmask, pv.order, pv.torder, out, (int)Vin, (int)Vout, Cin, Cout, K, nullptr, 0, 0, 0, nullptr};
+  LtConvTimerScope timed(stream, Cin, Cout, K, Vout);
+  const unsigned grid = (unsigned)(((Vout + LT_TM - 1) / LT_TM + 3) / 4);
+  if (Cout == 32) LT_CONV_LAUNCH(k_spconv_stem<32>, dim3(grid), dim3(256), stream, a, weight);
+  else LT_CONV_LAUNCH(k_spconv_stem<16>, dim3(grid), dim3(256), stream, a, weight);
+  LT_LAUNCH_CHECK();
+  return LT_OK;
+}
+
 template <int NT>
 static int launch_conv(const ConvArgs& a, hipStream_t stream) {
   dim3 grid(lt_cdiv(a.Vout, LT_TM), a.Cout / (16 * NT));

@@ -197,9 +197,16 @@ class _SparseConv(Function):
     def forward(ctx, feats, weight, kmap: KernelMap, transposed: bool, wcache=None):
         w = weight if weight.dim() == 3 else weight.unsqueeze(0)
         cout = w.shape[2]
-        packed = _packed(weight, 0, wcache)
         ctx.wcache = wcache
-        out = _run_conv(feats, packed, kmap, transposed, cout)
+        if feats.shape[1] == 4 and cout in (16, 32) and not transposed and feats.is_cuda:
+            # the network's first conv: streaming kernel, unpacked weights
+            if ops.CONV_PAIRS is not None:
+                if kmap._npairs is None:
+                    kmap._npairs = (kmap.results >= 0).sum()
+                ops.CONV_PAIRS.append(kmap._npairs)
+            out = ops.spconv_stem(feats, w, kmap.plan(), kmap.K, kmap.n_out)
+        else:
+            out = _run_conv(feats, _packed(weight, 0, wcache), kmap, transposed, cout)
         ctx.kmap, ctx.transposed = kmap, transposed
         ctx.save_for_backward(feats, weight)
         return out

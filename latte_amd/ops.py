@@ -238,6 +238,18 @@ def spconv(feats: torch.Tensor, packed: torch.Tensor, nbr: torch.Tensor, cout: i
     return out
 
 
+def spconv_stem(feats: torch.Tensor, weight: torch.Tensor, plan: torch.Tensor, K: int, Vout: int) -> torch.Tensor:
+    """the 4-channel first conv through its streaming kernel; weight = the unpacked kernel [K, 4, Cout] (Cout 16 | 32)"""
+    feats = _chk(feats, torch.float32, "spconv_stem feats")
+    w = _chk(weight.detach(), torch.float32, "spconv_stem weight")
+    assert w.dim() == 3 and w.shape[0] == K and w.shape[1] == 4 and feats.shape[1] == 4
+    cout = w.shape[2]
+    out = torch.empty((Vout, cout), dtype=torch.float32, device=feats.device)
+    _lib.call("lt_spconv_stem_fwd", _p(feats), _p(w), _p(plan), _p(out), feats.shape[0], Vout, 4, int(cout), int(K),
+              _stream())
+    return out
+
+
 def spconv_bwd_weight(feats, gout, nbmaps, nbsizes, K: int, cin: int, cout: int, transposed: bool = False):
     """dW [K,Cin,Cout] = per offset feats[in rows]^T @ gout[out rows] over the pair list (lt_spconv_bwd_weight)."""
     feats = _chk(feats, torch.float32, "bwd_weight feats")

@@ -670,3 +670,38 @@ def test_head_gather_matches_linear_then_gather(cin, c, dual):
         f3 = feats.clone().requires_grad_(True)
         (torch.nn.functional.linear(f3, w1, b1)[idx] * gw1).sum().backward()
         assert rel_err(f2.grad.cpu(), f3.grad) < 1e-5
+
+
+@pytest.mark.parametrize("cout", [32, 16])
+def test_stem_kernel_matches_oracle_and_scalar_kernel(scans_small, cout):
+    """lt_spconv_stem_fwd (4 input channels, one lane per output row) against the oracle conv and the MFMA table kernel."""
+    from latte_amd import ops
+    from latte_amd import functional as LF
+    c = scans_small["coords"]
+    nbmaps, nbsizes, out_coords, res = ts_ref.build_kmap(c, 1, 3, 1)
+    g = torch.Generator().manual_seed(cout)
+    feats = torch.randn(c.shape[0], 4, generator=g)
+    w = torch.randn(27, 4, cout, generator=g) / np.sqrt(27 * 4)
+    want = ts_ref.conv3d(feats, w, nbmaps, nbsizes, c.shape[0])
+    resd = dev(res, torch.int32)
+    plan = ops.kmap_plan(resd)
+    got = ops.spconv_stem(feats.cuda(), w.cuda(), plan, 27, c.shape[0])
+    assert rel_err(got.cpu(), want) < 1e-5
+    old = ops.spconv(feats.cuda(), ops.pack_weights(w.cuda(), 0), resd, cout)
+    assert rel_err(got.cpu(), old.cpu()) < 1e-6
+    assert torch.equal(got, ops.spconv_stem(feats.cuda(), w.cuda(), plan, 27, c.shape[0]))
+    # ragged tail / rows without any neighbour but themselves
+    V = 130
+    tbl = torch.full((27, V), -1, dtype=torch.int32)
+    tbl[13] = torch.arange(V, dtype=torch.int32)
+    tbl[0, 5], tbl[26, 129] = 7, 0
+    f = torch.randn(V, 4, generator=g)
+    o = ops.spconv_stem(f.cuda(), w.cuda(), ops.kmap_plan(tbl.cuda()), 27, V).cpu()
+    ref = f @ w[13]
+    ref[5] += f[7] @ w[0]
+    ref[129] += f[0] @ w[26]
+    assert torch.allclose(o, ref, rtol=1e-5, atol=1e-6)
+    # and through the module path (what SPVCNN's stem runs)
+    km = LF.KernelMap(resd, c.shape[0], c.shape[0], submanifold=True)
+    y = LF.sparse_conv(feats.cuda(), w.cuda(), km)
+    assert torch.equal(y, got)
