@@ -64,6 +64,8 @@ def parse():
                     "instead of one step ahead")
     ap.add_argument("--dump-conv", default=None, help="write the per-launch conv table of one step (JSON) here")
     ap.add_argument("--fwd-only", action="store_true", help="time teacher forward only")
+    ap.add_argument("--sync-bn", action="store_true", help="N > 1: cross-rank BatchNorm statistics (exact parity with the "
+                    "unsplit batch: ~150 small all-reduces per step) instead of per-GPU statistics")
     return ap.parse_args()
 
 
@@ -440,7 +442,8 @@ def main():
         scan_offset = shard_scan_offset(rank, w["B"])     # weak scaling: every rank owns its own B scans
     torch.manual_seed(1)  # cfg.RNG_SEED (latte/common/config/base.py:173); same weights on every rank
     model = Net3DSeg(w["C"], True, "SPVCNN", {"cr": args.cr}).to(dev)
-    step = LatteStep(model, w["C"], hr_cfg_of(w), process_group=pg, side_stream=not args.no_side_stream)
+    step = LatteStep(model, w["C"], hr_cfg_of(w), process_group=pg, side_stream=not args.no_side_stream,
+                     sync_bn=args.sync_bn)
     batch = build_batch(w_rank, device=dev, scan_offset=scan_offset, seed=rank)
     n_points_total = total_scans * w["n"]
 
@@ -490,6 +493,7 @@ def main():
             "config": {"workload": name, "scans_per_step": total_scans, "scans_per_gpu": w_rank["B"],
                        "points_per_scan": w["n"], "classes": w["C"], "st_window": w["W"], "st_voxel_m": w["vs"],
                        "max_range_m": w["R"], "spvcnn_cr": args.cr, "voxels_per_gpu": batch["n_voxels"],
+                       "batchnorm_statistics": "cross-rank (exact)" if (args.sync_bn and world > 1) else "per GPU",
                        "parallelism": f"dp{world} (whole sequences per rank, no data-path collective"
                                       + (", one flat RCCL all-reduce of the BatchNorm grads)" if world > 1 else ")"),
                        **({"strong_scaling_base": "python bench.py --gpus 1 --workload multiseq_64"}

@@ -252,6 +252,38 @@ def sparse_conv(feats, weight, kmap: KernelMap, transposed: bool = False, wcache
     return _SparseConv.apply(feats, weight, kmap, transposed, wcache)
 
 
+# Cross-rank BatchNorm statistics (SURVEY 8e "optional exact-parity mode").  None: every rank normalises with the
+# statistics of its own scans (the default of the sharded step; a documented deviation from one big batch).  A process
+# group: every BatchNorm all-reduces [sum x, sum x^2, rows] in the forward and [sum g, sum g*xhat] in the backward, so a
+# batch split over ranks gives the features and gradients of the unsplit batch (to fp32 rounding).  The parameter
+# gradients then ARE the global sums on every rank: the step must not all-reduce them again (LatteStep handles that).
+SYNC_BN_GROUP = None
+
+
+def _allreduce_small(t: torch.Tensor, group) -> torch.Tensor:
+    """sum all-reduce of a small device tensor (RCCL on GPU groups; through the host for gloo rehearsals)"""
+    import torch.distributed as dist
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        h = t.cpu()
+        dist.all_reduce(h, group=group)
+        return h.to(t.device)
+    dist.all_reduce(t, group=group)
+    return t
+
+
+def sync_batch_stats(mean: torch.Tensor, var: torch.Tensor, rows: int, group):
+    """local (mean, biased var, rows) of every rank -> global (mean, var, total rows); combined in fp64 from
+    [sum x, sum x^2, rows]"""
+    m, v = mean.double(), var.double()
+    vec = torch.cat([m * rows, (v + m * m) * rows, torch.tensor([float(rows)], dtype=torch.float64, device=mean.device)])
+    vec = _allreduce_small(vec, group)
+    C = mean.numel()
+    n = vec[2 * C]
+    gm = vec[:C] / n
+    gv = (vec[C:2 * C] / n - gm * gm).clamp_(min=0.0)
+    return gm.float(), gv.float(), n
+
+
 class _BatchNorm(Function):
     """BN with batch statistics, optional fused residual add and ReLU: y = relu(bn(x) + residual); post_add (with relu and
     a residual): y = relu(bn(x)) + residual, the sum after the activation (the point branch of SPVCNN)."""
@@ -259,6 +291,10 @@ class _BatchNorm(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, residual, eps, relu, stats_out, post_add=False):
         mean, var = ops.bn_stats(x)
+        ctx.sync = None
+        if SYNC_BN_GROUP is not None:
+            mean, var, n_total = sync_batch_stats(mean, var, x.shape[0], SYNC_BN_GROUP)
+            ctx.sync = (SYNC_BN_GROUP, n_total, x.shape[0])
         post_add = bool(post_add and relu and residual is not None)
         y = ops.bn_apply(x, mean, var, gamma, beta, eps, residual=residual, relu=relu, post_add=post_add)
         ctx.eps, ctx.relu, ctx.post_add = eps, relu, post_add
@@ -276,13 +312,21 @@ class _BatchNorm(Function):
         dy = dy.contiguous()
         need_dx = ctx.needs_input_grad[0]
         need_dres = ctx.has_res and ctx.needs_input_grad[3]
+        sync = None
+        if ctx.sync is not None:
+            group, n_total, rows = ctx.sync
+
+            def sync(sum_g, sum_gx):
+                both = _allreduce_small(torch.cat([sum_g, sum_gx]), group)
+                C = sum_g.numel()
+                return both[:C].contiguous(), both[C:].contiguous(), (rows / n_total).float()
         if ctx.post_add:
             # the residual bypasses the ReLU: its gradient is dy itself
             dx, dgamma, dbeta, _ = ops.bn_bwd(dy, x, None, mean, var, gamma, ctx.eps, True, need_dx=need_dx,
-                                              need_dres=False, beta=beta)
+                                              need_dres=False, beta=beta, sync=sync)
             return dx, dgamma, dbeta, (dy if need_dres else None), None, None, None, None
         dx, dgamma, dbeta, dres = ops.bn_bwd(dy, x, y, mean, var, gamma, ctx.eps, ctx.relu, need_dx=need_dx,
-                                             need_dres=need_dres, beta=beta)
+                                             need_dres=need_dres, beta=beta, sync=sync)
         return dx, dgamma, dbeta, dres, None, None, None, None
 
 

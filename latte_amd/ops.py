@@ -321,8 +321,11 @@ def _relu_mode(relu: bool, y, beta) -> int:
     return 2
 
 
-def bn_bwd(dy, x, y, mean, var, gamma, eps: float, relu: bool, need_dx=True, need_dres=False, beta=None):
-    """-> (dx | None, dgamma, dbeta, dres | None).  y None with relu: mask rebuilt from x (needs beta; no residual)."""
+def bn_bwd(dy, x, y, mean, var, gamma, eps: float, relu: bool, need_dx=True, need_dres=False, beta=None, sync=None):
+    """-> (dx | None, dgamma, dbeta, dres | None).  y None with relu: mask rebuilt from x (needs beta; no residual).
+    sync (optional): callable (sum_g, sum_gx) -> (sum_g, sum_gx, scale) applied between the column reduction and the
+    elementwise pass -- cross-rank BatchNorm: the sums become the global ones and the elementwise pass, which divides
+    by the LOCAL row count, gets them scaled by local rows / global rows."""
     dy = _chk(dy, torch.float32, "bn_bwd dy")
     x = _chk(x, torch.float32, "bn_bwd x")
     V, C = x.shape
@@ -338,9 +341,13 @@ def bn_bwd(dy, x, y, mean, var, gamma, eps: float, relu: bool, need_dx=True, nee
               ws.numel(), _p(sum_g), _p(sum_gx), _stream())
     dx = torch.empty_like(x) if need_dx else None
     dres = torch.empty_like(x) if need_dres else None
+    ag, agx = sum_g, sum_gx
+    if sync is not None:
+        sum_g, sum_gx, scale = sync(sum_g, sum_gx)
+        ag, agx = (sum_g * scale).contiguous(), (sum_gx * scale).contiguous()
     if need_dx or need_dres:
-        _lib.call("lt_bn_bwd_apply", _p(dy), _p(x), yp, _p(mean), _p(var), gp, bp, float(eps), mode, _p(sum_g),
-                  _p(sum_gx), _p(dx), _p(dres), V, C, _stream())
+        _lib.call("lt_bn_bwd_apply", _p(dy), _p(x), yp, _p(mean), _p(var), gp, bp, float(eps), mode, _p(ag),
+                  _p(agx), _p(dx), _p(dres), V, C, _stream())
     return dx, sum_gx, sum_g, dres
 
 

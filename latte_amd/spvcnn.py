@@ -37,8 +37,10 @@ def _conv_bn_impl(seq, x: SparseTensor, i: int, relu: bool, residual=None) -> Sp
     conv, bn = seq[i], seq[i + 1]
     batch_stats = bn.training or not bn.track_running_stats or bn.running_mean is None
     updates_running = bn.training and bn.track_running_stats and bn.running_mean is not None
+    from . import functional as LF
     if (conv.kernel_volume > 1 and conv.bias is None and x.feats.is_cuda and x.feats.shape[1] % 16 == 0
-            and batch_stats and not updates_running and not conv.kernel.requires_grad and x.feats.shape[0] > 1):
+            and batch_stats and not updates_running and not conv.kernel.requires_grad and x.feats.shape[0] > 1
+            and LF.SYNC_BN_GROUP is None):   # cross-rank statistics: the all-reduce sits between conv and BN apply
         y = spnn.conv3d_bn(x, conv, bn, relu=relu, residual=residual)
         if y is not None:
             return y

@@ -228,7 +228,7 @@ _KEEP_CACHE = bool(__import__("os").environ.get("LATTE_DIAG_KEEP_INDEX_CACHE"))
 class LatteStep:
     def __init__(self, model_3d: nn.Module, num_classes: int, hr_cfg: Dict, lr: float = 1e-3, conf_perc=None,
                  lambda_hr_23: float = 0.3, lambda_hr_32: float = 0.3, lambda_ety_ps: float = 1.0, class_weights=None,
-                 process_group=None, side_stream: bool = True, fused_optimizer: bool = True):
+                 process_group=None, side_stream: bool = True, fused_optimizer: bool = True, sync_bn: bool = False):
         self.model = configure_model_norm(model_3d, reset_dropout=True)
         self.ema_model = create_ema_model(self.model)
         self.hr = HR_Block(**hr_cfg)
@@ -249,6 +249,10 @@ class LatteStep:
         self.num_classes = num_classes
         self.pg = process_group
         self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
+        # sync_bn (N > 1 only): the exact-parity mode of SURVEY 8e -- BatchNorm statistics and their backward sums are
+        # all-reduced per layer, so the sharded step computes what ONE GPU would on the whole batch; the BatchNorm
+        # parameter gradients are then global sums on every rank and are not all-reduced again
+        self.sync_bn = bool(sync_bn) and self.world > 1
         self.timers = None
         self.trace = None
         # input-only, sync-heavy work (index structures, in-FOV tables, HR_Block.geometry) on a side stream: see
@@ -480,12 +484,16 @@ class LatteStep:
     def _update(self) -> None:
         """all-reduce (N > 1), optimizer step, EMA teacher update (latte.py:317-323)"""
         if not self.fused:
-            self.allreduce_grads()
+            if self.sync_bn:
+                for p in self.params:      # already the global sums of the per-rank losses: the mean over ranks
+                    p.grad.div_(self.world)
+            else:
+                self.allreduce_grads()
             self.optimizer.step()
             update_ema_norm(self.ema_model, self.model, 0.99, self._ema_pairs)
             return
         flat = self.optimizer.gather_grads()
-        if self.world > 1:
+        if self.world > 1 and not self.sync_bn:
             # the only collective of the path: ONE all-reduce (RCCL over xGMI) of the flat gradient buffer; the mean is
             # folded into the update kernel (grad_scale)
             if flat.is_cuda and torch.distributed.get_backend(self.pg) == "gloo":
@@ -495,6 +503,16 @@ class LatteStep:
             else:
                 torch.distributed.all_reduce(flat, group=self.pg)
         self.optimizer.step(grad_scale=1.0 / self.world)
+
+    def _with_sync_bn(self, fn, *args):
+        from . import functional as LF
+        if not self.sync_bn:
+            return fn(*args)
+        prev, LF.SYNC_BN_GROUP = LF.SYNC_BN_GROUP, self.pg
+        try:
+            return fn(*args)
+        finally:
+            LF.SYNC_BN_GROUP = prev
 
     def step(self, batch: Dict, next_batch: Dict | None = None):
         """One TTA iteration on `batch`.  next_batch (optional): the batch of the NEXT iteration -- a helper thread starts
@@ -508,7 +526,7 @@ class LatteStep:
         if next_batch is not None:
             self.prefetch(next_batch)
         self.optimizer.zero_grad(set_to_none=True)
-        losses = self.forward_backward(batch, pre)
+        losses = self._with_sync_bn(self.forward_backward, batch, pre)
         self._update()
         self._tick("optim_ema")
         return losses

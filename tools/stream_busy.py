@@ -18,7 +18,7 @@ def main():
     rows.sort()
     # one whole TTA step: from the start of the 4-channel stem conv of one teacher forward to the start of the next one
     # (k_spconv_scalar runs twice per step: teacher, student)
-    stem = [r[0] for r in rows if "k_spconv_scalar" in r[3]]
+    stem = [r[0] for r in rows if "k_spconv_stem" in r[3] or "k_spconv_scalar" in r[3]]
     nsteps = int(sys.argv[sys.argv.index("--steps") + 1]) if "--steps" in sys.argv else 2
     if len(stem) >= 2 * (nsteps + 1):
         lo, hi = stem[-2 * (nsteps + 1)], stem[-2]
