@@ -64,6 +64,9 @@ def parse():
                     "instead of one step ahead")
     ap.add_argument("--dump-conv", default=None, help="write the per-launch conv table of one step (JSON) here")
     ap.add_argument("--fwd-only", action="store_true", help="time teacher forward only")
+    ap.add_argument("--conv-precision", default="f32", choices=["f32", "bf16x3"], help="arithmetic of the sparse convs: fp32 "
+                    "MFMA (default, the headline) or the opt-in bf16x3 split-precision kernel (lt_conv_set_precision)")
+    ap.add_argument("--no-bf16x3-line", action="store_true", help="skip the extra bf16x3 measurement of the default run")
     ap.add_argument("--sync-bn", action="store_true", help="N > 1: cross-rank BatchNorm statistics (exact parity with the "
                     "unsplit batch: ~150 small all-reduces per step) instead of per-GPU statistics")
     return ap.parse_args()
@@ -423,6 +426,8 @@ def main():
             dist.init_process_group(backend)
         pg = dist.group.WORLD
 
+    from latte_amd import ops as _ops
+    _ops.set_conv_precision(args.conv_precision)
     name = args.workload or ("a2d2_kitti_128k" if world == 1 else "multiseq_64")
     w = synth.workload(name)
     scaling = "weak"
@@ -482,6 +487,23 @@ def main():
                                  "points_per_step": ob["n_points"], "voxels": ob["n_voxels"],
                                  "conv_tflops": oroof["achieved"], "conv_frac_mfma": oroof["frac"]}
                 del om, ostep, ob
+        bf = None
+        if (world == 1 and args.workload is None and args.conv_precision == "f32" and not args.no_bf16x3_line
+                and not args.fwd_only):
+            # the same step with the opt-in bf16x3 split-precision conv kernel (fp32-equivalent to ~1e-5; NOT the headline)
+            _ops.set_conv_precision("bf16x3")
+            torch.manual_seed(1)
+            bm = Net3DSeg(w["C"], True, "SPVCNN", {"cr": args.cr}).to(dev)
+            bstep = LatteStep(bm, w["C"], hr_cfg_of(w), side_stream=not args.no_side_stream)
+            br = time_steps(bstep, batch, args, 1, dev, backend, steps=args.steps, warmup=2)
+            broof = conv_roofline(br, argparse.Namespace(dump_conv=None))
+            bf = {"value": n_points_total * br["steps"] / br["dt"], "unit": "points/s",
+                  "ms_per_step": round(1e3 * br["dt"] / br["steps"], 3), "steps": br["steps"],
+                  "conv_tflops_fp32_equivalent": broof["achieved"], "conv_avg_launch_us": broof["avg_launch_us"],
+                  "note": "convs with >= 64 input channels on v_mfma_f32_16x16x32_bf16, operands split hi + lo in bf16, products "
+                          "hi*hi + hi*lo + lo*hi accumulated in fp32 (~1e-5 relative to the fp32 kernel); opt-in, never the headline"}
+            _ops.set_conv_precision("f32")
+            del bm, bstep
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(w, args.cr, args.cpu_scans)
@@ -503,6 +525,9 @@ def main():
         }
         if others is not None:
             out["other_workloads"] = others
+        if bf is not None:
+            out["bf16x3_mode"] = bf
+        out["config"]["conv_precision"] = args.conv_precision
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

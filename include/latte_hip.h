@@ -106,6 +106,7 @@ int lt_kmap_plan(const int32_t* table, int32_t K, int64_t V, void* ws, int64_t w
  *   mode 0: Wk            (forward, weight [K,Cin,Cout])
  *   mode 1: Wk^T          (transposed conv fwd's backward / strided conv backward: use with lt_kmap_reverse)
  *   mode 2: W(K-1-k)^T    (backward-input of a submanifold stride-1 conv on the SAME table)
+ *   mode 4 / 5 / 6: the bf16 hi|lo split images of modes 0 / 1 / 2 for the bf16x3 kernel (lt_conv_set_precision)
  * For modes 1,2 the packed matrix maps Cout -> Cin channels (swap Cin/Cout in lt_spconv_fwd).
  * Cin % 4 == 0 and Cout % 16 == 0 required; `order` (optional, [Vout]) is a processing permutation of the
  * output rows (locality / skip rate), results do not depend on it. */
@@ -149,6 +150,16 @@ int64_t lt_spconv_bwd_weight_workspace_bytes(int64_t M, int32_t K, int32_t Cin, 
 int lt_spconv_bwd_weight(const float* in, const float* gout, const int32_t* nbmaps, const int32_t* nbsizes, int64_t M,
                          int64_t Vin, int64_t Vout, int32_t Cin, int32_t Cout, int32_t K, int32_t transposed, void* ws,
                          int64_t ws_bytes, float* dW, lt_stream_t stream);
+
+/* Arithmetic of the planned conv kernels, process-wide (north_star: "bf16/fp32 MFMA tiles"; no counterpart in the reference,
+ * whose convs are fp32 GEMMs).  0 (default): fp32 MFMA, one reproducible fmaf chain per output.  1: bf16x3 split precision
+ * on v_mfma_f32_16x16x32_bf16 -- every fp32 operand is hi + lo in bf16, a product is hi*hi + hi*lo + lo*hi accumulated in
+ * fp32: ~1e-5 relative to the fp32 kernel (inside the 1e-3 bar, not bit-equal), 1.1-1.5x faster per conv.  It applies to
+ * the convs for which lt_conv_uses_bf16(Cin, Cout) is 1 (effective Cin >= 64 and a multiple of 32); THOSE convs' weights
+ * must be packed with lt_spconv_pack_weights mode 4 / 5 / 6 (the bf16 hi|lo images of modes 0 / 1 / 2).  All others keep
+ * fp32.  Explicit variants: lt_spconv_plan_fwd_v 3000 + 100*SR + 10*NTW + W (W in 1..4 divides Cin/32). */
+int lt_conv_set_precision(int32_t mode);
+int lt_conv_uses_bf16(int32_t Cin, int32_t Cout);
 
 /* Conv launch timer -- measurement aid, no counterpart in the reference (bench.py's roofline leg uses it).  Between
  * begin and end every sparse-conv kernel launch of this library (lt_spconv_fwd, lt_spconv_plan_fwd*, and the ones inside

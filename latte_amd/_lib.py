@@ -45,6 +45,8 @@ SIGNATURES = {
     "lt_spconv_plan_fwd": (ctypes.c_int, [P, P, P, P, I64, I64, I32, I32, I32, P]),
     "lt_spconv_plan_fwd_v": (ctypes.c_int, [P, P, P, P, I64, I64, I32, I32, I32, I32, P]),
     "lt_spconv_stat_blocks": (I64, [I64, I32]),
+    "lt_conv_set_precision": (ctypes.c_int, [I32]),
+    "lt_conv_uses_bf16": (ctypes.c_int, [I32, I32]),
     "lt_conv_timer_begin": (ctypes.c_int, [I32]),
     "lt_conv_timer_arm": (ctypes.c_int, [I32]),
     "lt_conv_timer_end": (I64, [P, P, I64]),

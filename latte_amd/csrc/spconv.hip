@@ -73,11 +73,23 @@ __global__ void k_pack_weights(const float* __restrict__ W, int K, int Cin, int 
 }
 
 extern "C" int64_t lt_spconv_packed_floats(int32_t K, int32_t Cin, int32_t Cout) { return (int64_t)K * Cin * Cout; }
+__global__ void k_pack_weights_bf16(const float* __restrict__ W, int K, int Cin, int Cout, int mode,
+                                    unsigned short* __restrict__ packed);
 
 extern "C" int lt_spconv_pack_weights(const float* W, int32_t K, int32_t Cin, int32_t Cout, int32_t mode,
                                       float* packed, hipStream_t stream) {
   LT_REQUIRE(W && packed, LT_ERR_ARG, "lt_spconv_pack_weights: null pointer");
-  LT_REQUIRE(K >= 1 && Cin >= 1 && Cout >= 1 && mode >= 0 && mode <= 2, LT_ERR_ARG, "lt_spconv_pack_weights: bad args");
+  LT_REQUIRE(K >= 1 && Cin >= 1 && Cout >= 1 && mode >= 0 && mode <= 6 && mode != 3, LT_ERR_ARG, "lt_spconv_pack_weights: bad args");
+  if (mode >= 4) {  // bf16 hi/lo split image of modes 0..2 for the bf16x3 kernel (see k_spconv_bf)
+    const int ce_in = mode == 4 ? Cin : Cout, ce_out = mode == 4 ? Cout : Cin;
+    LT_REQUIRE(ce_in % 32 == 0 && ce_out % 16 == 0, LT_ERR_ARG,
+               "lt_spconv_pack_weights: bf16 image needs effective Cin=%d %% 32 == 0 and Cout=%d %% 16 == 0", ce_in, ce_out);
+    const int64_t tot = (int64_t)K * Cin * Cout;
+    hipLaunchKernelGGL(k_pack_weights_bf16, dim3(lt_grid(tot, 256)), dim3(256), 0, stream, W, K, Cin, Cout, mode,
+                       reinterpret_cast<unsigned short*>(packed));
+    LT_LAUNCH_CHECK();
+    return LT_OK;
+  }
   const int Ce_in = mode == 0 ? Cin : Cout, Ce_out = mode == 0 ? Cout : Cin;
   LT_REQUIRE(Ce_in % 4 == 0 && Ce_out % 16 == 0, LT_ERR_ARG,
              "lt_spconv_pack_weights: effective Cin=%d must be a multiple of 4 and Cout=%d of 16", Ce_in, Ce_out);
@@ -1184,6 +1196,297 @@ static int launch_sj(const PlanArgs& a, int sr, int ntw, int w, hipStream_t stre
   return LT_OK;
 }
 
+// =====================================================================================================
+// bf16x3 split-precision kernel (opt-in: lt_spconv_plan_fwd_v variant 3000 + 100*SR + 10*NTW + W, pack mode 4).
+//
+// Same decomposition as k_spconv_sj (output-stationary, W waves split the channel groups of every active offset, partial
+// sums added in wave order), but the contraction runs on the bf16 matrix pipe: every fp32 operand is split into
+// hi = bf16(x) and lo = bf16(x - hi), and a product is hi*hi + hi*lo + lo*hi accumulated in fp32 by the MFMA (the dropped
+// lo*lo term and the rounding of lo are ~2^-17 relative per product: features agree with the fp32 kernel to ~1e-5, two
+// orders inside the 1e-3 bar, but NOT bit for bit).  One v_mfma_f32_16x16x32_bf16 (16 cycles) contracts 32 channels where
+// the fp32 kernel needs eight v_mfma_f32_16x16x4_f32 (256 cycles): with three products per tile the matrix pipe has 5.3x
+// less to do and the kernel becomes bound by operand delivery.
+//  * unit of work: a channel PAIR-group jp (32 channels).  A: lane (r, q) loads 32 contiguous bytes of row nbr[k][r] at
+//    channel 32 jp + 8 q (MFMA k index 8 q + e <-> channel 32 jp + 8 q + e) and splits them in registers (v_cvt_pk_bf16_f32);
+//  * B: split once at pack time (mode 4): per (k, jp, n-tile) 2 KiB = the hi operand image (64 lanes x 16 B) followed by the
+//    lo image -- the same bytes per weight as fp32, two 16-B loads per tile, no conversion in the kernel.
+// Needs Cin % 32 == 0 and (Cin / 32) % W == 0.
+typedef __bf16 lt_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__global__ void k_pack_weights_bf16(const float* __restrict__ W, int K, int Cin, int Cout, int mode,
+                                    unsigned short* __restrict__ packed) {
+  // mode 4: E = Wk; 5: Wk^T; 6: W(K-1-k)^T  (modes 0, 1, 2 of the fp32 image)
+  const int m = mode - 4;
+  const int Ce_in = m == 0 ? Cin : Cout;
+  const int Ce_out = m == 0 ? Cout : Cin;
+  const int NTt = Ce_out / 16, JP = Ce_in / 32;
+  const int64_t total = (int64_t)K * Ce_in * Ce_out;  // (hi, lo) pairs
+  for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = p;
+    const int e = (int)(r & 7); r >>= 3;
+    const int lane = (int)(r & 63); r >>= 6;
+    const int nt = (int)(r % NTt); r /= NTt;
+    const int jp = (int)(r % JP);
+    const int k = (int)(r / JP);
+    const int ci = 32 * jp + 8 * (lane >> 4) + e;
+    const int co = 16 * nt + (lane & 15);
+    float v;
+    if (m == 0) v = W[((int64_t)k * Cin + ci) * Cout + co];
+    else {
+      const int ks = m == 2 ? (K - 1 - k) : k;
+      v = W[((int64_t)ks * Cin + co) * Cout + ci];
+    }
+    const __bf16 hi = (__bf16)v;
+    const __bf16 lo = (__bf16)(v - (float)hi);
+    const int64_t base = ((((int64_t)k * JP + jp) * NTt + nt) * 2) * 512 + lane * 8 + e;   // in bf16 units
+    packed[base] = __builtin_bit_cast(unsigned short, hi);
+    packed[base + 512] = __builtin_bit_cast(unsigned short, lo);
+  }
+}
+
+// 8 fp32 -> (hi, lo) bf16x8 operands
+__device__ __forceinline__ void lt_split_bf16(const f32x4& x0, const f32x4& x1, lt_bf16x8& hi, lt_bf16x8& lo) {
+  typedef float f32x8 __attribute__((ext_vector_type(8)));
+  const f32x8 x = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+  hi = __builtin_convertvector(x, lt_bf16x8);
+  const u32x4 hb = __builtin_bit_cast(u32x4, hi);
+  f32x8 back;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    back[2 * i] = __uint_as_float(hb[i] << 16);
+    back[2 * i + 1] = __uint_as_float(hb[i] & 0xFFFF0000u);
+  }
+  lo = __builtin_convertvector(x - back, lt_bf16x8);
+}
+
+template <int SR, int NTW, int W>
+__global__ __launch_bounds__(64 * W) void k_spconv_bf(PlanArgs a) {
+  constexpr int PARTS = SR >= 4 ? 1 : 4 / SR;
+  constexpr int TMW = 16 * SR;
+  __shared__ int s_nbr[LT_KMAX * TMW];
+  __shared__ int s_rows[TMW];
+  __shared__ int s_klist[LT_KMAX];
+  __shared__ unsigned int s_act[LT_KMAX];
+  __shared__ int s_nact;
+  __shared__ f32x4 s_red[W * NTW * 64];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  const unsigned gy = a.Cout / (16 * NTW);
+  unsigned bx, by;
+  {
+    const unsigned L = blockIdx.x, i = L >> 3;   // XCD-aware mapping (see k_spconv_rf)
+    bx = (i / gy) * 8 + (L & 7);
+    by = i % gy;
+  }
+  if (bx >= (unsigned)a.gx || by >= gy) return;
+  const int64_t tile0 = (int64_t)a.torder[bx / PARTS];
+  const int s0 = PARTS == 1 ? 0 : (int)(bx % PARTS) * SR;
+  const int JP = a.Cin / 32, NTt = a.Cout / 16;
+  const int JPW = JP / W;
+  const int nt0 = by * NTW;
+
+  if (wave == 0) {
+    unsigned int act = 0u;
+    unsigned long long m = 0ull;
+    if (lane < a.K) m = a.tmask[tile0 * a.K + lane];
+#pragma unroll
+    for (int st = 0; st < SR; ++st)
+      if ((m >> (16 * (s0 + st))) & 0xFFFFull) act |= 1u << st;
+    const unsigned long long bal = __ballot(act != 0u);
+    if (act != 0u) {
+      const int pos = __popcll(bal & ((1ull << lane) - 1ull));
+      s_klist[pos] = lane;
+      s_act[pos] = act;
+    }
+    if (lane == 0) s_nact = __popcll(bal);
+  }
+  for (int i = tid; i < TMW; i += 64 * W) {
+    const int64_t slot = tile0 * LT_TM + 16 * s0 + i;
+    s_rows[i] = slot < a.Vout ? a.order[slot] : -1;
+  }
+  __syncthreads();
+  const int nact = s_nact;
+  for (int e = tid; e < nact * TMW; e += 64 * W) {
+    const int ki = e / TMW, i = e - ki * TMW;
+    int v = a.tnbr[(tile0 * a.K + s_klist[ki]) * LT_TM + 16 * s0 + i];
+    if (v >= a.Vin) v = -1;
+    s_nbr[e] = v;
+  }
+  __syncthreads();
+
+  f32x4 acc[SR][NTW];
+#pragma unroll
+  for (int h = 0; h < SR; ++h)
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) acc[h][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0,
+                                                                        (int)((int64_t)a.Vin * a.Cin * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.packed), 0,
+                                                                        (int)((int64_t)a.K * a.Cin * a.Cout * 4), 0x00020000);
+  const int lane_a = (8 * q + 32 * wave) * 4;       // bytes into a gathered row: this wave's first pair-group
+  const int lane_b = lane * 16;
+  const int row_bytes = a.Cin * 4;
+  const int wstep = W * NTt * 2048;                 // pair-group jp -> jp + W in the packed image
+  const int wkstep = JP * NTt * 2048;               // offset k -> k + 1
+  const int wbase = (wave * NTt + nt0) * 2048;
+
+  const int U = nact * JPW;                         // units (offset, pair-group) of this wave
+  if (U > 0) {
+    // unit u = (ki, jj): operands are loaded one unit ahead of the MFMAs
+    f32x4 a0[SR], a1[SR];
+    u32x4 bh[NTW], bl[NTW];
+    unsigned int act_nxt = 0u;
+    auto load_unit = [&](int u) {
+      const int ki = u / JPW, jj = u - ki * JPW;
+      const int k = s_klist[ki];
+      act_nxt = s_act[ki];
+      const int so_a = jj * 128 * W;
+      const int so_b = wbase + k * wkstep + jj * wstep;
+#pragma unroll
+      for (int h = 0; h < SR; ++h) {
+        const int nb = s_nbr[ki * TMW + 16 * h + r];
+        const int vo = nb >= 0 ? nb * row_bytes + lane_a : 0x7FFFF000;   // past the end: the hardware returns zeros
+        a0[h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, vo, so_a, 0));
+        a1[h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, vo, so_a + 16, 0));
+      }
+#pragma unroll
+      for (int n = 0; n < NTW; ++n) {
+        bh[n] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, lane_b + n * 2048, so_b, 0));
+        bl[n] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, lane_b + n * 2048 + 1024, so_b, 0));
+      }
+    };
+    load_unit(0);
+    for (int u = 0; u < U; ++u) {
+      // operands of unit u into MFMA form, then the next unit's loads go out under this unit's MFMAs
+      const unsigned int act = act_nxt;
+      lt_bf16x8 ah[SR], al[SR], wh[NTW], wl[NTW];
+#pragma unroll
+      for (int h = 0; h < SR; ++h) lt_split_bf16(a0[h], a1[h], ah[h], al[h]);
+#pragma unroll
+      for (int n = 0; n < NTW; ++n) {
+        wh[n] = __builtin_bit_cast(lt_bf16x8, bh[n]);
+        wl[n] = __builtin_bit_cast(lt_bf16x8, bl[n]);
+      }
+      if (u + 1 < U) load_unit(u + 1);
+#pragma unroll
+      for (int h = 0; h < SR; ++h) {
+        if ((act >> h) & 1u) {   // wave-uniform
+#pragma unroll
+          for (int n = 0; n < NTW; ++n) acc[h][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[h], wh[n], acc[h][n], 0, 0, 0);
+#pragma unroll
+          for (int n = 0; n < NTW; ++n) acc[h][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[h], wl[n], acc[h][n], 0, 0, 0);
+#pragma unroll
+          for (int n = 0; n < NTW; ++n) acc[h][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[h], wh[n], acc[h][n], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // epilogue: as k_spconv_sj (strip h finished by wave h % W, partials through LDS in wave order, column sums)
+  float s1[NTW], s2[NTW];
+#pragma unroll
+  for (int n = 0; n < NTW; ++n) s1[n] = s2[n] = 0.f;
+#pragma unroll
+  for (int h = 0; h < SR; ++h) {
+    const int owner = h % W;
+    f32x4* red = s_red;
+    if (W > 1) {
+      if (h > 0) __syncthreads();
+      if (wave != owner) {
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) red[(wave * NTW + n) * 64 + lane] = acc[h][n];
+      }
+      __syncthreads();
+    }
+    if (wave == owner) {
+#pragma unroll
+      for (int n = 0; n < NTW; ++n) {
+        f32x4 sum = (owner == 0 || W == 1) ? acc[h][n] : red[n * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < W; ++w) {
+          const f32x4 v = w == owner ? acc[h][n] : red[(w * NTW + n) * 64 + lane];
+          sum[0] += v[0]; sum[1] += v[1]; sum[2] += v[2]; sum[3] += v[3];
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int row = s_rows[16 * h + 4 * q + reg];
+          if (row >= 0) a.out[(int64_t)row * a.Cout + 16 * (nt0 + n) + r] = sum[reg];
+          s1[n] += sum[reg];
+          s2[n] += sum[reg] * sum[reg];
+        }
+      }
+    }
+  }
+  if (a.partial) {
+    float* redf = reinterpret_cast<float*>(s_red);
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) {
+      float t1 = s1[n], t2 = s2[n];
+      t1 += __shfl_xor(t1, 16, 64); t2 += __shfl_xor(t2, 16, 64);
+      t1 += __shfl_xor(t1, 32, 64); t2 += __shfl_xor(t2, 32, 64);
+      if (q == 0) {
+        redf[((wave * NTW + n) * 2 + 0) * 16 + r] = t1;
+        redf[((wave * NTW + n) * 2 + 1) * 16 + r] = t2;
+      }
+    }
+    __syncthreads();
+    if (wave == 0 && lane < 32) {
+      const int which = lane >> 4;
+#pragma unroll
+      for (int n = 0; n < NTW; ++n) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < W; ++w) t += redf[((w * NTW + n) * 2 + which) * 16 + r];
+        a.partial[((int64_t)bx * 2 + which) * a.Cout + 16 * (nt0 + n) + r] = t;
+      }
+    }
+  }
+}
+
+template <int SR, int NTW, int W>
+static void launch_bf_one(const PlanArgs& a, hipStream_t stream) {
+  const unsigned gx = (unsigned)(((a.Vout + LT_TM - 1) / LT_TM) * (SR >= 4 ? 1 : 4 / SR));
+  PlanArgs b = a;
+  b.gx = (int)gx;
+  const unsigned gy = (unsigned)(a.Cout / (16 * NTW));
+  const unsigned total = ((gx + 7) / 8) * 8 * gy;
+  LT_CONV_LAUNCH((k_spconv_bf<SR, NTW, W>), dim3(total), dim3(64 * W), stream, b);
+}
+
+static bool bf_supported(int Cin, int Cout, int sr, int ntw, int w) {
+  return Cin % 32 == 0 && (sr == 1 || sr == 2 || sr == 4) && (ntw == 2 || ntw == 3 || ntw == 4) && (Cout / 16) % ntw == 0 &&
+         (w == 1 || w == 2 || w == 3 || w == 4) && (Cin / 32) % w == 0;
+}
+static int launch_bf(const PlanArgs& a, int sr, int ntw, int w, hipStream_t stream) {
+#define LT_BF_W(SRv, NTWv)                                          \
+  do {                                                              \
+    switch (w) {                                                    \
+      case 4: launch_bf_one<SRv, NTWv, 4>(a, stream); break;        \
+      case 3: launch_bf_one<SRv, NTWv, 3>(a, stream); break;        \
+      case 2: launch_bf_one<SRv, NTWv, 2>(a, stream); break;        \
+      default: launch_bf_one<SRv, NTWv, 1>(a, stream); break;       \
+    }                                                               \
+  } while (0)
+#define LT_BF_NTW(SRv)                                              \
+  do {                                                              \
+    if (ntw == 4) LT_BF_W(SRv, 4);                                  \
+    else if (ntw == 3) LT_BF_W(SRv, 3);                             \
+    else LT_BF_W(SRv, 2);                                           \
+  } while (0)
+  if (sr == 4) LT_BF_NTW(4);
+  else if (sr == 2) LT_BF_NTW(2);
+  else LT_BF_NTW(1);
+#undef LT_BF_NTW
+#undef LT_BF_W
+  LT_LAUNCH_CHECK();
+  return LT_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Conv launch timer (bench.py's roofline leg): while armed, every sparse-conv kernel launch of this library is bracketed
 // by two hipEvents on the stream the kernel is launched on (attached to the dispatch itself, hipExtLaunchKernelGGL).  Process-global, one caller thread (as everywhere).
@@ -1258,7 +1561,21 @@ extern "C" int64_t lt_conv_timer_end(float* ms, int32_t* meta, int64_t capacity)
 // levels with enough rows that the coarser work items still fill the chip many times over -- measured per level at the
 // a2d2_kitti_128k sizes (tools/cb_a2d2.sh): 310 k rows, C=96: 377 -> 349 us; 141 k rows: 173 -> 164 us; below ~100 k rows
 // the shorter tail of 16-row workgroups wins.  A function of Vout only: lt_spconv_stat_blocks must agree with it.
-static int conv_default_sr(int64_t Vout) { return Vout >= 100000 ? 2 : 1; }
+// Process-wide arithmetic of the planned conv kernels: 0 = fp32 MFMA (default; bit-reproducible fmaf chains), 1 = bf16x3 split
+// precision (k_spconv_bf) for every conv whose effective Cin is a multiple of 32 and at least 64; the caller packs the
+// weights of exactly those convs with mode 4..6 (lt_conv_uses_bf16 is the rule, for both sides).
+static int g_conv_precision = 0;
+static int conv_default_sr(int64_t Vout) { return g_conv_precision ? 2 : (Vout >= 100000 ? 2 : 1); }
+static bool conv_uses_bf16(int Cin, int Cout) {
+  return g_conv_precision == 1 && Cin >= 64 && Cin % 32 == 0 && Cout >= 32 && Cout % 16 == 0;
+}
+extern "C" int lt_conv_set_precision(int32_t mode) {
+  LT_REQUIRE(mode == 0 || mode == 1, LT_ERR_ARG, "lt_conv_set_precision: mode %d not in {0 (fp32), 1 (bf16x3)}", mode);
+  g_conv_precision = mode;
+  return LT_OK;
+}
+extern "C" int lt_conv_uses_bf16(int32_t Cin, int32_t Cout) { return conv_uses_bf16(Cin, Cout) ? 1 : 0; }
+
 
 struct LtConvShape {
   int sr, ntw, w;
@@ -1325,6 +1642,12 @@ static int spconv_plan_impl(const float* in, const float* packed, const void* pl
   LtConvTimerScope timed(stream, Cin, Cout, K, Vout);
   const int ntt = Cout / 16;
   LT_REQUIRE(!(partial && variant != 0), LT_ERR_ARG, "lt_spconv_plan_fwd: statistics need the default variant");
+  if (variant == 0 && conv_uses_bf16(Cin, Cout) && Vin * Cin * 4 < 0x7FFFF000ll && (int64_t)K * Cin * Cout * 4 < 0x7FFFF000ll) {
+    // bf16x3: 32-row workgroups on every level, channel pair-groups over two waves when their count is even (measured per
+    // level at the a2d2 sizes, tools/cb_bf16.py)
+    const int jp = Cin / 32;
+    return launch_bf(a, 2, ntt % 4 == 0 ? 4 : ntt % 3 == 0 ? 3 : 2, jp % 2 == 0 ? 2 : 1, stream);
+  }
   if (variant == 0) {
     const LtConvShape sh = conv_default_shape(Vin, Vout, Cin, Cout, K);
     static const bool no_sj = getenv("LT_CONV_NO_SPLITJ") != nullptr;  // A/B measurements: the flat split-k loop
@@ -1349,6 +1672,21 @@ static int spconv_plan_impl(const float* in, const float* packed, const void* pl
     a.swz = 0;
     variant -= 10000;
     LT_REQUIRE(variant >= 1000, LT_ERR_ARG, "lt_spconv_plan_fwd_v: unknown variant %d", variant + 10000);
+  }
+  if (variant >= 3000 && variant < 4000) {  // bf16x3 split precision (packed with mode 4..6): 3000 + 100*SR + 10*NTW + W; 3000 = default shape
+    int v = variant - 3000;
+    if (v == 0) {
+      const int jp = Cin / 32;
+      const int nw = ntt % 4 == 0 ? 4 : ntt % 3 == 0 ? 3 : 2;
+      const int ww = jp % 2 == 0 ? 2 : (jp % 3 == 0 ? 3 : 1);
+      v = 100 * (Vout >= 100000 ? 4 : 2) + 10 * nw + ww;
+    }
+    sr = v / 100;
+    ntw = (v / 10) % 10;
+    const int w = v % 10;
+    LT_REQUIRE(bf_supported(Cin, Cout, sr, ntw, w) && Vin * Cin * 4 < 0x7FFFF000ll && (int64_t)K * Cin * Cout * 4 < 0x7FFFF000ll,
+               LT_ERR_ARG, "lt_spconv_plan_fwd_v: bad bf16x3 variant %d for Cin=%d Cout=%d", variant, Cin, Cout);
+    return launch_bf(a, sr, ntw, w, stream);
   }
   if (variant >= 2000 && variant < 3000) {  // split-j: 2000 + 100*SR + 10*NTW + W
     const int v = variant - 2000;

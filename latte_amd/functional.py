@@ -180,14 +180,17 @@ def _packed(weight, mode: int, cache: dict | None):
     """MFMA-fragment image of `weight`, re-packed only when the parameter changed (under TRAIN.UPDATE_PARAMS == "norm"
     the conv kernels are frozen: latte/common/utils/ema_util.py:16-24); see PACK_EPOCH above for what "changed" covers."""
     w = weight if weight.dim() == 3 else weight.unsqueeze(0)
+    # effective (Cin, Cout) of the product this image feeds: modes 1, 2 are the transposed (backward-input) matrices
+    ce_in, ce_out = (w.shape[1], w.shape[2]) if mode == 0 else (w.shape[2], w.shape[1])
+    pmode = mode + 4 if (ops.CONV_PRECISION != "f32" and ops.conv_uses_bf16(ce_in, ce_out)) else mode
     if cache is None:
-        return ops.pack_weights(w, mode)
-    tag = (weight._version, weight.data_ptr(), PACK_EPOCH)
+        return ops.pack_weights(w, pmode)
+    tag = (weight._version, weight.data_ptr(), PACK_EPOCH, pmode)
     hit = cache.get(mode)
     if hit is not None and hit[0] == tag:
         return hit[1]
     _register_kernel(weight)
-    packed = ops.pack_weights(w, mode)
+    packed = ops.pack_weights(w, pmode)
     cache[mode] = (tag, packed)
     return packed
 

@@ -190,6 +190,22 @@ def pack_weights(weight: torch.Tensor, mode: int = 0) -> torch.Tensor:
     return packed
 
 
+CONV_PRECISION = "f32"
+
+
+def set_conv_precision(name: str) -> None:
+    """'f32' (default) or 'bf16x3' (split-precision bf16 MFMA for the convs with >= 64 input channels): process-wide, see
+    lt_conv_set_precision.  Packed weight images made under the other setting are re-made (the cache tag carries it)."""
+    global CONV_PRECISION
+    mode = {"f32": 0, "fp32": 0, "bf16x3": 1}[name]
+    _lib.call("lt_conv_set_precision", mode)
+    CONV_PRECISION = "bf16x3" if mode else "f32"
+
+
+def conv_uses_bf16(cin: int, cout: int) -> bool:
+    return CONV_PRECISION != "f32" and bool(_lib.load().lt_conv_uses_bf16(int(cin), int(cout)))
+
+
 def conv_timer_begin(capacity: int) -> None:
     """bench.py's kernel timer: until conv_timer_end() the library brackets every sparse-conv kernel launch with two HIP
     events on the stream the kernel is launched on (lt_conv_timer_begin)."""

@@ -203,3 +203,51 @@ def test_spvcnn_bn_gradients_match_oracle_to_1e3_under_one_relu_pattern(scans_sm
     print("BN-grad rel errs under one ReLU pattern (worst 4):", errs[:4], "median", errs[len(errs) // 2][0])
     assert errs[len(errs) // 2][0] < RTOL
     assert errs[0][0] < RTOL, errs[0]
+
+
+def test_bf16x3_conv_mode_stays_inside_the_parity_bar(scans_small):
+    """Opt-in bf16x3 split-precision convs (lt_conv_set_precision(1)): the backbone's logits against the CPU oracle stay
+    inside the 1e-3 bar (measured ~1e-5), per-conv error vs the fp32 kernel ~5e-6, backward-input included; switching back
+    restores the bit-exact fp32 path."""
+    from latte_amd import ops
+    from latte_amd import functional as LF
+    from latte_amd.tensor import SparseTensor
+    from oracle.spvcnn_ref import SPVCNNRef
+    m = make_model(1.0)
+    ref = SPVCNNRef(m.state_dict())
+    coords, feats = scans_small["coords"], torch.from_numpy(scans_small["feats"])
+    with torch.no_grad():
+        want = ref(coords, feats)
+    mg = m.cuda()
+    lidar = SparseTensor(feats.cuda(), torch.from_numpy(coords).cuda(), 1)
+    with torch.no_grad():
+        base = mg({"lidar": lidar})["seg_logit"].clone()
+    try:
+        ops.set_conv_precision("bf16x3")
+        assert ops.conv_uses_bf16(96, 96) and not ops.conv_uses_bf16(32, 32) and not ops.conv_uses_bf16(48, 48)
+        with torch.no_grad():
+            got = mg({"lidar": lidar})
+        for k in ("feats", "seg_logit", "seg_logit2"):
+            e = rel_err(got[k].cpu(), want[k])
+            assert e < 2e-4, (k, e)
+        assert not torch.equal(got["seg_logit"], base)            # a different arithmetic really ran
+        # one conv, forward and backward-input, against the fp32 kernel
+        from latte_amd import sparse_modules as spnn
+        g = torch.Generator().manual_seed(8)
+        conv = spnn.Conv3d(96, 128, 3).cuda()
+        conv.kernel.requires_grad_(False)
+        f = torch.randn(coords.shape[0], 96, generator=g).cuda().requires_grad_(True)
+        y16 = conv(SparseTensor(f, lidar.C, 1)).F
+        gy = torch.randn(y16.shape, generator=g).cuda()
+        y16.backward(gy)
+        g16 = f.grad.clone()
+        ops.set_conv_precision("f32")
+        f.grad = None
+        y32 = conv(SparseTensor(f, lidar.C, 1)).F
+        y32.backward(gy)
+        assert 0 < rel_err(y16.detach(), y32.detach()) < 2e-5 and 0 < rel_err(g16, f.grad) < 2e-5
+    finally:
+        ops.set_conv_precision("f32")
+    with torch.no_grad():
+        again = mg({"lidar": lidar})["seg_logit"]
+    assert torch.equal(again, base)

@@ -169,7 +169,8 @@ def test_fused_and_unfused_update_give_the_same_step():
         l2 = {k: float(v) for k, v in step.step(batch).items()}
         out.append((sd, l1, l2))
     (sd_f, l1_f, l2_f), (sd_u, l1_u, l2_u) = out
-    assert l1_f == l1_u                                      # same forward / backward before the first update
+    for k in l1_f:                                           # same forward / backward before the first update (the
+        assert abs(l1_f[k] - l1_u[k]) <= 1e-6 * abs(l1_u[k])  # step's torch index_add atomics leave ~1 ulp of run-to-run noise)
     for which in (0, 1):
         for (ka, va), (kb, vb) in zip(sd_f[which].items(), sd_u[which].items()):
             assert ka == kb and torch.allclose(va, vb, rtol=1e-5, atol=3e-7), ka
