@@ -35,7 +35,9 @@ int lt_sphash(const int32_t* coords, int64_t n, const int32_t* offsets, int32_t 
 
 /* torchsparse.nn.functional.sphashquery(queries, references)  (torchsparse_utils.py:17,46,74)
  * build: table over `keys` (value = row index; duplicate keys keep the smallest index)
- * query: out[i] = index of queries[i] in keys, -1 on miss. `n_build` must be the n given to build. */
+ * query: out[i] = index of queries[i] in keys, -1 on miss. `n_build` must be the n given to build.
+ * RESERVED KEY: int64 -1 (all bits set) marks an empty slot of the table; a key with that value is never found and, in
+ * lt_unique_sorted, never reported (sphash folds to 60 bits and the voxel keys are non-negative: neither produces it). */
 int64_t lt_table_bytes(int64_t n);
 int lt_hash_build(const int64_t* keys, int64_t n, void* table, int64_t table_bytes, lt_stream_t stream);
 int lt_hash_query(const int64_t* queries, int64_t q, const void* table, int64_t n_build, int64_t* out,

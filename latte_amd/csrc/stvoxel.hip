@@ -405,10 +405,15 @@ extern "C" int lt_st_join(const int64_t* a_keys, int64_t Va, const int64_t* t_ke
 }
 
 // ---------------------------------------------------------------- class-wise quantile mask (refine_ety)
-__global__ void k_cq_keys(const float* __restrict__ ety, const int* __restrict__ label, int64_t n, int64_t* __restrict__ keys) {
+// labels outside [0, num_classes) (an ignore label such as -100, or a class the caller did not count) belong to no class:
+// they sort into the segment 0xFFFF, which no threshold is computed for, and k_cq_mask keeps them
+__global__ void k_cq_keys(const float* __restrict__ ety, const int* __restrict__ label, int64_t n, int num_classes,
+                          int64_t* __restrict__ keys) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const unsigned int bits = __float_as_uint(ety[i] + 0.0f);  // ety >= 0: IEEE bit pattern is order-preserving
-    keys[i] = ((int64_t)(label[i] & 0xFFFF) << 32) | (int64_t)bits;
+    const int l = label[i];
+    const int64_t cls = (l >= 0 && l < num_classes) ? l : 0xFFFF;
+    keys[i] = (cls << 32) | (int64_t)bits;
   }
 }
 
@@ -443,9 +448,11 @@ __global__ void k_cq_thresh(const int64_t* __restrict__ skeys, int64_t n, int nu
 }
 
 __global__ void k_cq_mask(const float* __restrict__ ety, const int* __restrict__ label, int64_t n, const float* __restrict__ thresh,
-                          int mode, unsigned char* __restrict__ mask) {
+                          int num_classes, int mode, unsigned char* __restrict__ mask) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const float t = thresh[label[i]];
+    const int l = label[i];
+    if (l < 0 || l >= num_classes) { mask[i] = 1; continue; }   // no class: never masked
+    const float t = thresh[l];
     mask[i] = mode == 0 ? ((ety[i] > t) ? 0 : 1) : ((ety[i] < t) ? 0 : 1);
   }
 }
@@ -477,7 +484,7 @@ extern "C" int lt_class_median_mask(const float* vals, const int32_t* label, int
 
 static int class_mask_impl(const float* ety, const int32_t* label, int64_t n, int32_t num_classes, float q, int mode,
                            void* ws, int64_t ws_bytes, uint8_t* mask, hipStream_t stream) {
-  LT_REQUIRE(n >= 0 && num_classes >= 1 && num_classes <= 65535, LT_ERR_ARG, "lt_class_quantile_mask: bad sizes");
+  LT_REQUIRE(n >= 0 && num_classes >= 1 && num_classes < 65535, LT_ERR_ARG, "lt_class_quantile_mask: bad sizes");
   LT_REQUIRE(q >= 0.f && q <= 1.f, LT_ERR_ARG, "lt_class_quantile_mask: q must be in [0,1]");
   if (n == 0) return LT_OK;
   LT_REQUIRE(ety && label && ws && mask, LT_ERR_ARG, "lt_class_quantile_mask: null pointer");
@@ -489,14 +496,14 @@ static int class_mask_impl(const float* ety, const int32_t* label, int64_t n, in
   const int64_t sb = cq_sort_bytes(n);
   void* tmp = a.take(sb);
   LT_REQUIRE(keys && skeys && thresh && tmp, LT_ERR_WORKSPACE, "lt_class_quantile_mask: arena exhausted");
-  hipLaunchKernelGGL(k_cq_keys, dim3(lt_grid(n, 256)), dim3(256), 0, stream, ety, label, n, keys);
+  hipLaunchKernelGGL(k_cq_keys, dim3(lt_grid(n, 256)), dim3(256), 0, stream, ety, label, n, num_classes, keys);
   LT_LAUNCH_CHECK();
   size_t sbs = (size_t)sb;
   LT_CHECK_HIP(rocprim::radix_sort_keys<LtSortConfig>(tmp, sbs, keys, skeys, (size_t)n, 0, 48, stream));
   hipLaunchKernelGGL(k_cq_thresh, dim3(lt_cdiv(num_classes, 64)), dim3(64), 0, stream, skeys, n, num_classes, q, mode,
                      thresh);
   LT_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_cq_mask, dim3(lt_grid(n, 256)), dim3(256), 0, stream, ety, label, n, thresh, mode, mask);
+  hipLaunchKernelGGL(k_cq_mask, dim3(lt_grid(n, 256)), dim3(256), 0, stream, ety, label, n, thresh, num_classes, mode, mask);
   LT_LAUNCH_CHECK();
   return LT_OK;
 }

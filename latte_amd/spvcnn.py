@@ -104,6 +104,11 @@ class SPVCNN(nn.Module):
         super().__init__()
         cr = kwargs.get("cr", 1.0)
         cs = [int(cr * c) for c in _BASE_CHANNELS]
+        if any(c < 16 or c % 16 for c in cs):
+            # the MFMA conv kernels tile channels by 16 (csrc/spconv.hip); the reference's configs use cr = 1.0 (0.5 in its
+            # smoke test, latte/models/xmuda_arch.py:485-599)
+            raise ValueError(f"SPVCNN(cr={cr}): channel widths {cs} must be multiples of 16 on this backend "
+                             "(cr = 1.0 and 0.5 are; 0.25 or 0.75 are not)")
         self.pres = self.vres = 0.05
         self.out_channels = cs[8]
 

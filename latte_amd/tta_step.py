@@ -225,6 +225,9 @@ def _record_stream_tree(obj, stream, seen=None) -> None:
 _KEEP_CACHE = bool(__import__("os").environ.get("LATTE_DIAG_KEEP_INDEX_CACHE"))
 
 
+_SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
+
+
 class LatteStep:
     def __init__(self, model_3d: nn.Module, num_classes: int, hr_cfg: Dict, lr: float = 1e-3, conf_perc=None,
                  lambda_hr_23: float = 0.3, lambda_hr_32: float = 0.3, lambda_ety_ps: float = 1.0, class_weights=None,
@@ -307,7 +310,15 @@ class LatteStep:
         if not (self.hr_side_stream and self.timers is None):
             return None
         if self._side is None:
-            self._side = torch.cuda.Stream(priority=int(__import__("os").environ.get("LATTE_DIAG_SIDE_PRIORITY", "-1")))  # small dependent kernels: ahead of the big ones
+            # ONE side stream per device for the whole process: a process has few hardware queues (GPU_MAX_HW_QUEUES = 4 on
+            # the box) and HIP deals streams onto them round-robin, so a fresh stream per LatteStep instance eventually
+            # lands on the main stream's queue and the "side" work queues up behind the convs (measured: the 4th
+            # instance of a process ran 45 ms per step instead of 29)
+            dev = torch.cuda.current_device()
+            if dev not in _SIDE_STREAMS:
+                prio = int(__import__("os").environ.get("LATTE_DIAG_SIDE_PRIORITY", "-1"))  # small dependent kernels: ahead of the big ones
+                _SIDE_STREAMS[dev] = torch.cuda.Stream(priority=prio)
+            self._side = _SIDE_STREAMS[dev]
         return self._side
 
     def _hr_inputs(self, batch: Dict, tab: Dict):

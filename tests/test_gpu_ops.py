@@ -705,3 +705,30 @@ def test_stem_kernel_matches_oracle_and_scalar_kernel(scans_small, cout):
     km = LF.KernelMap(resd, c.shape[0], c.shape[0], submanifold=True)
     y = LF.sparse_conv(feats.cuda(), w.cuda(), km)
     assert torch.equal(y, got)
+
+
+def test_conv_epilogue_statistics_with_a_large_mean(scans_small):
+    """The fused conv+BN statistics are E[x^2] - E[x]^2 from un-shifted fp32 per-workgroup sums (fp64 combination): the
+    relative error of var grows like 1e-7 * (1 + mean^2/var).  Known-answer check at |mean|/std ~ 30 (conv outputs of the
+    network sit at O(1)): var within 1e-7 * (1 + ratio^2) * 8 of the shifted two-pass lt_bn_stats, mean within 1e-6."""
+    from latte_amd import ops
+    from latte_amd import functional as LF
+    c = scans_small["coords"]
+    _, _, _, res = ts_ref.build_kmap(c, 1, 3, 1)
+    resd = dev(res, torch.int32)
+    plan = ops.kmap_plan(resd)
+    V = c.shape[0]
+    g = torch.Generator().manual_seed(12)
+    feats = torch.randn(V, 32, generator=g).cuda()
+    w = torch.zeros(27, 32, 32)
+    w[13] = torch.eye(32)                       # centre offset only: conv output = input + constant shift below
+    feats = feats + 30.0
+    packed = ops.pack_weights(w.cuda(), 0)
+    gamma, beta = torch.ones(32, device="cuda"), torch.zeros(32, device="cuda")
+    conv_out, y, mean, var = ops.conv_bn_fwd(feats, packed, plan, 27, V, 32, gamma, beta, 1e-5, None, False)
+    assert torch.equal(conv_out, feats)
+    m2, v2 = ops.bn_stats(conv_out)
+    ratio2 = float((m2 * m2 / v2).max())
+    assert 500 < ratio2 < 2000
+    assert torch.allclose(mean, m2, rtol=1e-6)
+    assert float(((var - v2).abs() / v2).max()) < 1e-7 * (1 + ratio2) * 8

@@ -203,3 +203,23 @@ def test_quantile_rejects_bad_arguments():
         ops.quantile(torch.zeros(0, device="cuda"), 0.5)
     with pytest.raises(RuntimeError):
         ops.quantile(torch.zeros(8, device="cuda"), 1.5)
+
+
+def test_class_masks_ignore_labels_outside_the_class_range():
+    """refine_ety / refine_pseudo_labels with an ignore label (-100) or a label >= num_classes among the inputs: those
+    entries belong to no class -- never masked, and no out-of-bounds threshold read."""
+    from latte_amd import ops
+    g = torch.Generator().manual_seed(2)
+    n = 4096
+    ety = torch.rand(n, generator=g)
+    lab = torch.randint(0, 5, (n,), generator=g)
+    odd = torch.rand(n, generator=g) < 0.1
+    lab_odd = lab.clone()
+    lab_odd[odd] = -100
+    lab_odd[odd & (torch.arange(n) % 2 == 0)] = 7
+    m_ref = ops.class_quantile_mask(ety[~odd].cuda(), lab[~odd].int().cuda(), 5, 0.75).cpu()
+    m = ops.class_quantile_mask(ety.cuda(), lab_odd.int().cuda(), 5, 0.75).cpu()
+    assert bool(m[odd].all()) and torch.equal(m[~odd], m_ref)
+    k_ref = ops.class_median_mask(ety[~odd].cuda(), lab[~odd].int().cuda(), 5, 0.9).cpu()
+    k = ops.class_median_mask(ety.cuda(), lab_odd.int().cuda(), 5, 0.9).cpu()
+    assert bool(k[odd].all()) and torch.equal(k[~odd], k_ref)
