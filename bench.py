@@ -67,6 +67,7 @@ def parse():
     ap.add_argument("--conv-precision", default="f32", choices=["f32", "bf16x3"], help="arithmetic of the sparse convs: fp32 "
                     "MFMA (default, the headline) or the opt-in bf16x3 split-precision kernel (lt_conv_set_precision)")
     ap.add_argument("--no-bf16x3-line", action="store_true", help="skip the extra bf16x3 measurement of the default run")
+    ap.add_argument("--no-scaling-base", action="store_true", help="N > 1: skip rank 0's one-GPU run of the whole 64-scan step")
     ap.add_argument("--sync-bn", action="store_true", help="N > 1: cross-rank BatchNorm statistics (exact parity with the "
                     "unsplit batch: ~150 small all-reduces per step) instead of per-GPU statistics")
     return ap.parse_args()
@@ -504,6 +505,19 @@ def main():
                           "hi*hi + hi*lo + lo*hi accumulated in fp32 (~1e-5 relative to the fp32 kernel); opt-in, never the headline"}
             _ops.set_conv_precision("f32")
             del bm, bstep
+        base1 = None
+        if world > 1 and scaling == "strong" and not args.no_scaling_base:
+            # the strong-scaling base in the SAME run: rank 0 alone takes the whole 64-scan step (the other ranks wait at
+            # the barrier below), so value / base value is the speed-up over one GPU on identical work
+            torch.manual_seed(1)
+            m1 = Net3DSeg(w["C"], True, "SPVCNN", {"cr": args.cr}).to(dev)
+            s1 = LatteStep(m1, w["C"], hr_cfg_of(w), side_stream=not args.no_side_stream)
+            b1 = build_batch(w, device=dev, scan_offset=0, seed=0)
+            r1 = time_steps(s1, b1, args, 1, dev, backend, steps=max(3, args.steps // 3), warmup=1, kernel_events=False)
+            base1 = {"n_gpus": 1, "workload": name, "ms_per_step": round(1e3 * r1["dt"] / r1["steps"], 3),
+                     "value": n_points_total * r1["steps"] / r1["dt"], "unit": "points/s", "steps": r1["steps"],
+                     "speedup_of_this_run": round((r1["dt"] / r1["steps"]) / (dt / args.steps), 3)}
+            del m1, s1, b1
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(w, args.cr, args.cpu_scans)
@@ -527,9 +541,12 @@ def main():
             out["other_workloads"] = others
         if bf is not None:
             out["bf16x3_mode"] = bf
+        if base1 is not None:
+            out["strong_scaling_base_measured"] = base1
         out["config"]["conv_precision"] = args.conv_precision
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()      # ranks > 0 wait here while rank 0 measures the one-GPU base
         dist.destroy_process_group()
 
 
