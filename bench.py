@@ -122,6 +122,7 @@ def cpu_baseline(w, cr, n_scans=None):
               f"fp32: {full['seconds']} s with {all_cores} threads, {omp4['seconds']} s with {omp4['cores']} threads "
               f"(the reference pins OMP_NUM_THREADS=4); the reference's own backend (torchsparse v1.4.0 CUDA) cannot run here")
     return {"value": full["value"], "unit": "points/s", "cores": all_cores, "kind": "port", "sample": sample,
+            "cpu_model": _cpu_model(),
             "omp4": {"value": omp4["value"], "unit": "points/s", "cores": omp4["cores"], "seconds": omp4["seconds"]},
             "seconds": full["seconds"]}
 
@@ -143,6 +144,37 @@ def _event_us(fn, reps=10, rounds=3):
         torch.cuda.synchronize()
         best = min(best, 1e3 * e0.elapsed_time(e1) / reps)
     return best
+
+
+def measured_peaks(dev):
+    """The two roofs re-measured on this box: a 1 GiB device copy (read + write bytes / time) and a dense
+    fp32 GEMM through torch (hipBLASLt), HIP events.  Reported beside the spec peaks the fractions are priced against."""
+    import torch
+    n = 1 << 28
+    a = torch.empty(n, dtype=torch.float32, device=dev).normal_()
+    b = torch.empty_like(a)
+    us = _event_us(lambda: b.copy_(a), reps=5)
+    copy = 2.0 * 4 * n / us / 1e3
+    del a, b
+    m = 8192
+    x = torch.randn(m, m, device=dev)
+    y = torch.randn(m, m, device=dev)
+    prev = torch.backends.cuda.matmul.allow_tf32
+    torch.backends.cuda.matmul.allow_tf32 = False
+    us = _event_us(lambda: torch.mm(x, y), reps=5)
+    torch.backends.cuda.matmul.allow_tf32 = prev
+    return {"copy_GBs": round(copy, 1), "copy_what": "torch copy_ of 1 GiB fp32 (read + write bytes)",
+            "sgemm_TFLOPs": round(2.0 * m ** 3 / us / 1e6, 1), "sgemm_what": "torch.mm 8192^3 fp32 (hipBLASLt)"}
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def hbm_classes(batch, w, hr):
@@ -472,6 +504,7 @@ def main():
                     pass
             if world == 1 and not args.no_hbm_classes and not args.fwd_only:
                 roof["hbm_classes"] = hbm_classes(batch, w, step.hr)
+                roof["peaks_measured_on_this_box"] = measured_peaks(dev)
         others = None
         if world == 1 and args.workload is None and not args.no_other_workloads and not args.fwd_only:
             others = {}

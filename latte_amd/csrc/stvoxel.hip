@@ -18,34 +18,60 @@
 #define ST_MASKED 0x7FFFFFFFFFFFFFFFll
 
 // ---------------------------------------------------------------- softmax + entropy
-__global__ void k_softmax_entropy(const float* __restrict__ logits, int64_t P, int C, float* __restrict__ probs,
-                                  float* __restrict__ ety) {
+// v[] lives in registers: every loop over the classes is unrolled to the compile-time bound CM (16 / 32 / 64) and guarded by
+// c < C -- a runtime-bounded loop over v[] would put the array into scratch memory (272 B per lane).
+template <int CM>
+__device__ __forceinline__ float st_softmax_entropy(const float* __restrict__ row, int C, float log2c, float (&v)[CM]) {
 #pragma clang fp contract(off)
+  float mx = -INFINITY;
+#pragma unroll
+  for (int c = 0; c < CM; ++c)
+    if (c < C) { v[c] = row[c]; mx = fmaxf(mx, v[c]); }
+  float sum = 0.f;
+#pragma unroll
+  for (int c = 0; c < CM; ++c)
+    if (c < C) { v[c] = expf(v[c] - mx); sum += v[c]; }
+  float e = 0.f;
+#pragma unroll
+  for (int c = 0; c < CM; ++c)
+    if (c < C) {
+      v[c] = v[c] / sum;
+      e += (-(v[c] * log2f(v[c] + 1e-30f))) / log2c;
+    }
+  return e;
+}
+
+template <int CM>
+__global__ __launch_bounds__(128) void k_softmax_entropy(const float* __restrict__ logits, int64_t P, int C, float* __restrict__ probs,
+                                  float* __restrict__ ety) {
   const float log2c = (float)log2((double)C);
   for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < P; p += (int64_t)gridDim.x * blockDim.x) {
-    const float* row = logits + p * C;
-    float v[64];
-    float mx = -INFINITY;
-#pragma unroll 4
-    for (int c = 0; c < C; ++c) { v[c] = row[c]; mx = fmaxf(mx, v[c]); }
-    float sum = 0.f;
-    for (int c = 0; c < C; ++c) { v[c] = expf(v[c] - mx); sum += v[c]; }
-    float e = 0.f;
-    for (int c = 0; c < C; ++c) {
-      const float pr = v[c] / sum;
-      if (probs) probs[p * C + c] = pr;
-      e += (-(pr * log2f(pr + 1e-30f))) / log2c;
+    float v[CM];
+    const float e = st_softmax_entropy<CM>(logits + p * C, C, log2c, v);
+    if (probs) {
+#pragma unroll
+      for (int c = 0; c < CM; ++c)
+        if (c < C) probs[p * C + c] = v[c];
     }
     if (ety) ety[p] = e;
   }
 }
+
+#define ST_CM_DISPATCH(C, CALL)            \
+  do {                                     \
+    if ((C) <= 16) { CALL(16); }           \
+    else if ((C) <= 32) { CALL(32); }      \
+    else { CALL(64); }                     \
+  } while (0)
 
 extern "C" int lt_softmax_entropy(const float* logits, int64_t P, int32_t C, float* probs, float* ety,
                                   hipStream_t stream) {
   LT_REQUIRE(P >= 0 && C >= 1 && C <= 64, LT_ERR_ARG, "lt_softmax_entropy: C=%d must be in [1,64]", C);
   if (P == 0) return LT_OK;
   LT_REQUIRE(logits && (probs || ety), LT_ERR_ARG, "lt_softmax_entropy: null pointer");
-  hipLaunchKernelGGL(k_softmax_entropy, dim3(lt_grid(P, 128)), dim3(128), 0, stream, logits, P, C, probs, ety);
+#define ST_CALL(CM) hipLaunchKernelGGL(k_softmax_entropy<CM>, dim3(lt_grid(P, 128)), dim3(128), 0, stream, logits, P, C, probs, ety)
+  ST_CM_DISPATCH(C, ST_CALL);
+#undef ST_CALL
   LT_LAUNCH_CHECK();
   return LT_OK;
 }
@@ -517,51 +543,42 @@ static int class_mask_impl(const float* ety, const int32_t* label, int64_t n, in
 //        with w2 = rv2/(rv2+rv3), w3 = rv3/(rv2+rv3), rv = exp(-pc)                                      latte.py:224-233
 //   ps_conf, ps_label = ps_prob.max(1)                                                                   latte.py:235
 // Pass 1 (k_pl_points3d) runs over all N points, pass 2 (k_pl_fov) over the Nf in-FOV points and overwrites their rows.
-__device__ __forceinline__ float pl_softmax_entropy(const float* row, int C, float* v) {
-#pragma clang fp contract(off)
-  const float log2c = (float)log2((double)C);
-  float mx = -INFINITY;
-  for (int c = 0; c < C; ++c) { v[c] = row[c]; mx = fmaxf(mx, v[c]); }
-  float sum = 0.f;
-  for (int c = 0; c < C; ++c) { v[c] = expf(v[c] - mx); sum += v[c]; }
-  float e = 0.f;
-  for (int c = 0; c < C; ++c) {
-    v[c] = v[c] / sum;
-    e += (-(v[c] * log2f(v[c] + 1e-30f))) / log2c;
-  }
-  return e;
-}
-
-__global__ void k_pl_points3d(const float* __restrict__ logits3, const float* __restrict__ st3, const float* __restrict__ thr3,
+template <int CM>
+__global__ __launch_bounds__(128) void k_pl_points3d(const float* __restrict__ logits3, const float* __restrict__ st3, const float* __restrict__ thr3,
                               int64_t N, int C, float* __restrict__ probs3, float* __restrict__ pc3,
                               float* __restrict__ conf, int* __restrict__ label) {
   const float t = thr3 ? *thr3 : INFINITY;
+  const float log2c = (float)log2((double)C);
   for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < N; p += (int64_t)gridDim.x * blockDim.x) {
-    float v[64];
-    float e = pl_softmax_entropy(logits3 + p * C, C, v);
+    float v[CM];
+    float e = st_softmax_entropy<CM>(logits3 + p * C, C, log2c, v);
     const float s = st3[p];
     if (s != 0.f && s <= t) e = s;
     pc3[p] = e;
     float best = v[0];
     int arg = 0;
-    for (int c = 0; c < C; ++c) {
-      probs3[p * C + c] = v[c];
-      if (v[c] > best) { best = v[c]; arg = c; }
-    }
+#pragma unroll
+    for (int c = 0; c < CM; ++c)
+      if (c < C) {
+        probs3[p * C + c] = v[c];
+        if (v[c] > best) { best = v[c]; arg = c; }
+      }
     conf[p] = best;
     label[p] = arg;
   }
 }
 
-__global__ void k_pl_fov(const float* __restrict__ logits2, const float* __restrict__ st2, const float* __restrict__ thr2,
+template <int CM>
+__global__ __launch_bounds__(128) void k_pl_fov(const float* __restrict__ logits2, const float* __restrict__ st2, const float* __restrict__ thr2,
                          const int64_t* __restrict__ fov_idx, const float* __restrict__ probs3,
                          const float* __restrict__ pc3, int64_t Nf, int C, float* __restrict__ pc2,
                          float* __restrict__ conf, int* __restrict__ label) {
 #pragma clang fp contract(off)
   const float t = thr2 ? *thr2 : INFINITY;
+  const float log2c = (float)log2((double)C);
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < Nf; i += (int64_t)gridDim.x * blockDim.x) {
-    float v[64];
-    float e = pl_softmax_entropy(logits2 + i * C, C, v);
+    float v[CM];
+    float e = st_softmax_entropy<CM>(logits2 + i * C, C, log2c, v);
     const float s = st2[i];
     if (s != 0.f && s <= t) e = s;
     pc2[i] = e;
@@ -570,10 +587,12 @@ __global__ void k_pl_fov(const float* __restrict__ logits2, const float* __restr
     const float w2 = rv2 / (rv2 + rv3), w3 = rv3 / (rv2 + rv3);
     float best = -INFINITY;
     int arg = 0;
-    for (int c = 0; c < C; ++c) {
-      const float m = w2 * v[c] + w3 * probs3[p * C + c];
-      if (m > best) { best = m; arg = c; }
-    }
+#pragma unroll
+    for (int c = 0; c < CM; ++c)
+      if (c < C) {
+        const float m = w2 * v[c] + w3 * probs3[p * C + c];
+        if (m > best) { best = m; arg = c; }
+      }
     conf[p] = best;
     label[p] = arg;
   }
@@ -587,13 +606,19 @@ extern "C" int lt_pseudo_label_fuse(const float* logits_2d, const float* logits_
   if (N == 0) return LT_OK;
   LT_REQUIRE(logits_3d && st_ety_3d && probs_3d && pc_3d && ps_conf && ps_label, LT_ERR_ARG,
              "lt_pseudo_label_fuse: null pointer");
-  hipLaunchKernelGGL(k_pl_points3d, dim3(lt_grid(N, 128)), dim3(128), 0, stream, logits_3d, st_ety_3d, thr_3d, N, C,
-                     probs_3d, pc_3d, ps_conf, ps_label);
+#define ST_CALL(CM)                                                                                                  \
+  hipLaunchKernelGGL(k_pl_points3d<CM>, dim3(lt_grid(N, 128)), dim3(128), 0, stream, logits_3d, st_ety_3d, thr_3d, N, C, \
+                     probs_3d, pc_3d, ps_conf, ps_label)
+  ST_CM_DISPATCH(C, ST_CALL);
+#undef ST_CALL
   LT_LAUNCH_CHECK();
   if (Nf > 0) {
     LT_REQUIRE(logits_2d && fov_idx && st_ety_2d && pc_2d, LT_ERR_ARG, "lt_pseudo_label_fuse: null pointer");
-    hipLaunchKernelGGL(k_pl_fov, dim3(lt_grid(Nf, 128)), dim3(128), 0, stream, logits_2d, st_ety_2d, thr_2d, fov_idx,
-                       probs_3d, pc_3d, Nf, C, pc_2d, ps_conf, ps_label);
+#define ST_CALL(CM)                                                                                                  \
+  hipLaunchKernelGGL(k_pl_fov<CM>, dim3(lt_grid(Nf, 128)), dim3(128), 0, stream, logits_2d, st_ety_2d, thr_2d, fov_idx, \
+                     probs_3d, pc_3d, Nf, C, pc_2d, ps_conf, ps_label)
+    ST_CM_DISPATCH(C, ST_CALL);
+#undef ST_CALL
     LT_LAUNCH_CHECK();
   }
   return LT_OK;
