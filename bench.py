@@ -405,7 +405,7 @@ def conv_roofline(r, args):
     achieved = flops_total / (ms_total * 1e-3) / 1e12
     return {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-            "kernel": "sparse-conv family (k_spconv_sj<SR,NTW,W> split-j fp32 MFMA; 4-channel stem: k_spconv_scalar): every "
+            "kernel": "sparse-conv family (k_spconv_sj<SR,NTW,W> split-j fp32 MFMA; 4-channel stem: k_spconv_stem): every "
                       "conv launch of the sampled steps of the timed region",
             "launches": launches, "avg_launch_us": round(1e3 * ms_total / launches, 2),
             "flops_per_launch": round(flops_total / launches),
