@@ -68,6 +68,8 @@ def parse():
                     "MFMA (default, the headline) or the opt-in bf16x3 split-precision kernel (lt_conv_set_precision)")
     ap.add_argument("--no-bf16x3-line", action="store_true", help="skip the extra bf16x3 measurement of the default run")
     ap.add_argument("--no-scaling-base", action="store_true", help="N > 1: skip rank 0's one-GPU run of the whole 64-scan step")
+    ap.add_argument("--emulate-shard", type=int, default=0, help="diagnostic, one GPU: time the step of rank 0's shard of "
+                    "multiseq_64 split over this many ranks (what one rank of an N-GPU run computes; no collective)")
     ap.add_argument("--sync-bn", action="store_true", help="N > 1: cross-rank BatchNorm statistics (exact parity with the "
                     "unsplit batch: ~150 small all-reduces per step) instead of per-GPU statistics")
     return ap.parse_args()
@@ -472,6 +474,9 @@ def main():
             raise SystemExit(f"multiseq_64 has {n_seq} sequences: at most {n_seq} ranks")
         s0, ns = shard_sequences(n_seq, world, rank)
         total_scans = w["B"]
+        if args.emulate_shard > 1 and world == 1:
+            s0, ns = shard_sequences(n_seq, args.emulate_shard, 0)
+            total_scans = ns * w["seq_len"]
         w_rank = dict(w, B=ns * w["seq_len"])
         scan_offset = s0 * w["seq_len"]
         scaling = "strong"
@@ -577,6 +582,8 @@ def main():
         if base1 is not None:
             out["strong_scaling_base_measured"] = base1
         out["config"]["conv_precision"] = args.conv_precision
+        if args.emulate_shard > 1 and world == 1:
+            out["metric"] = f"DIAGNOSTIC: one rank's shard of multiseq_64 over {args.emulate_shard} ranks, timed alone on one GPU"
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()      # ranks > 0 wait here while rank 0 measures the one-GPU base

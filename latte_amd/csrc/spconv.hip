@@ -986,9 +986,10 @@ __global__ __launch_bounds__(64 * W) void k_spconv_sj(PlanArgs a) {
       if (ki < nact) {
         const int k = __builtin_amdgcn_readlane(kl_v, ki);
         act_cur = (unsigned int)__builtin_amdgcn_readlane((int)act_v, ki);
-        soff_b = wbase + k * wkstep;
+        soff_b = wbase + ((a.dbg & 1) ? 0 : k) * wkstep;  // dbg & 1 / & 2: diagnostics with cache-resident weights / rows
 #pragma unroll
-        for (int h = 0; h < SR; ++h) voff[h] = srcn[h] >= 0 ? srcn[h] * row_bytes + lane_a : 0x7FFFF000;
+        for (int h = 0; h < SR; ++h)
+          voff[h] = srcn[h] >= 0 ? ((a.dbg & 2) ? (srcn[h] & 1023) : srcn[h]) * row_bytes + lane_a : 0x7FFFF000;
         const int kn = ki + 1 < nact ? ki + 1 : ki;
 #pragma unroll
         for (int h = 0; h < SR; ++h) srcn[h] = s_nbr[kn * TMW + 16 * h + r];
