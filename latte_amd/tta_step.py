@@ -23,7 +23,7 @@ from .functional import gather_rows
 from .hr_module import CR_Block, HR_Block
 from .spvcnn import inverse_to_all
 
-__all__ = ["configure_model_norm", "create_ema_model", "update_ema_norm", "refine_pseudo_labels", "pc2img_logit",
+__all__ = ["configure_model_norm", "configure_model_all", "create_ema_model", "update_ema_norm", "update_ema_all", "refine_pseudo_labels", "pc2img_logit",
            "LatteStep", "FlatAdamEMA", "shard_scan_offset", "shard_sequences", "allreduce_mean_grads"]
 
 
@@ -41,6 +41,26 @@ def configure_model_norm(model: nn.Module, reset_dropout: bool = True):
                 m.running_var = None
         elif reset_dropout and "dropout" in name:
             m.p = 0.0
+    return model
+
+
+def configure_model_all(model: nn.Module, reset_dropout: bool = True):
+    """ema_util.configure_model_all (TRAIN.UPDATE_PARAMS == "all"): train mode, EVERY parameter trainable (the reference
+    walks named_modules and enables grad on every module that is neither norm nor dropout -- the root module included),
+    BatchNorm on batch statistics, dropout reset on request."""
+    model.train()
+    model.requires_grad_(False)
+    for _, m in model.named_modules():
+        name = type(m).__name__.lower()
+        if "norm" in name:
+            m.requires_grad_(True)
+            m.track_running_stats = False
+            m.running_mean = None
+            m.running_var = None
+        elif reset_dropout and "dropout" in name:
+            m.p = 0.0
+        else:
+            m.requires_grad_(True)
     return model
 
 
@@ -69,6 +89,17 @@ def update_ema_norm(ema_model: nn.Module, model: nn.Module, alpha: float = 0.99,
     e, s = params if params is not None else (_norm_params(ema_model), _norm_params(model))
     torch._foreach_mul_(e, alpha)
     torch._foreach_add_(e, s, alpha=1.0 - alpha)
+    return ema_model
+
+
+@torch.no_grad()
+def update_ema_all(ema_model: nn.Module, model: nn.Module, alpha: float = 0.99, params=None) -> nn.Module:
+    """ema = alpha*ema + (1-alpha)*student on EVERY parameter (ema_util.update_ema_all, TRAIN.UPDATE_PARAMS == "all")."""
+    e, s = params if params is not None else (list(ema_model.parameters()), list(model.parameters()))
+    torch._foreach_mul_(e, alpha)
+    torch._foreach_add_(e, s, alpha=1.0 - alpha)
+    from . import functional as LF
+    LF.bump_pack_epoch()   # the teacher's conv kernels changed: their packed MFMA images are stale
     return ema_model
 
 
@@ -132,7 +163,12 @@ class FlatAdamEMA:
     buffer the RCCL all-reduce runs on -- and lt_adam_ema_step does Adam + EMA in one kernel.  Same hyper-parameter
     names and defaults as torch.optim.Adam (amsgrad / maximize are not supported)."""
 
-    def __init__(self, params, ema_params=None, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, ema_alpha=0.99):
+    def __init__(self, params, ema_params=None, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, ema_alpha=0.99,
+                 allow_missing_grads=False):
+        # allow_missing_grads: a parameter without a gradient counts as a zero gradient (update_params="all": the second
+        # head is outside the Latte losses).  torch.optim.Adam skips such a parameter instead; the result is the same
+        # while weight_decay == 0 and the parameter never gets a gradient later (its moments stay zero).
+        self.allow_missing = bool(allow_missing_grads)
         self.params = list(params)
         if not self.params:
             raise ValueError("FlatAdamEMA: no parameters")
@@ -171,12 +207,35 @@ class FlatAdamEMA:
     def gather_grads(self) -> torch.Tensor:
         """p.grad of every parameter -> the flat gradient buffer (one multi-tensor copy)"""
         grads = [p.grad for p in self.params]
+        if any(g is None for g in grads) and self.allow_missing:
+            have = [(v, g) for v, g in zip(self.g_views, grads) if g is not None]
+            for v, g in zip(self.g_views, grads):
+                if g is None:
+                    v.zero_()
+            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+            return self.flat_g
         if any(g is None for g in grads):
             missing = [i for i, g in enumerate(grads) if g is None]
             raise RuntimeError(f"FlatAdamEMA: parameters {missing[:4]}... have no gradient; every norm layer of SPVCNN is on "
                                "the path of the TTA losses, so this is a broken graph")
         torch._foreach_copy_(self.g_views, grads)
         return self.flat_g
+
+    def state_dict(self) -> Dict:
+        """optimizer state for checkpoint / resume (the parameters themselves are in the models' state_dicts)"""
+        return {"steps": self.steps, "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(),
+                "hyper": {"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay,
+                          "ema_alpha": self.ema_alpha}}
+
+    def load_state_dict(self, state: Dict) -> None:
+        if state["exp_avg"].numel() != self.exp_avg.numel():
+            raise ValueError(f"FlatAdamEMA.load_state_dict: {state['exp_avg'].numel()} scalars in the checkpoint, "
+                             f"{self.exp_avg.numel()} in this optimizer")
+        self.steps = int(state["steps"])
+        self.exp_avg.copy_(state["exp_avg"])
+        self.exp_avg_sq.copy_(state["exp_avg_sq"])
+        for k, v in state.get("hyper", {}).items():
+            setattr(self, k, tuple(v) if k == "betas" else v)
 
     def step(self, grad_scale: float = 1.0) -> None:
         self.steps += 1
@@ -231,19 +290,33 @@ _SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
 class LatteStep:
     def __init__(self, model_3d: nn.Module, num_classes: int, hr_cfg: Dict, lr: float = 1e-3, conf_perc=None,
                  lambda_hr_23: float = 0.3, lambda_hr_32: float = 0.3, lambda_ety_ps: float = 1.0, class_weights=None,
-                 process_group=None, side_stream: bool = True, fused_optimizer: bool = True, sync_bn: bool = False):
-        self.model = configure_model_norm(model_3d, reset_dropout=True)
+                 process_group=None, side_stream: bool = True, fused_optimizer: bool = True, sync_bn: bool = False,
+                 update_params: str = "norm"):
+        # update_params: cfg.TRAIN.UPDATE_PARAMS (latte/tta/tta.py:129-138) -- "norm" (every shipped latte.yaml: only the
+        # norm layers' gamma / beta train) or "all" (every parameter trains: conv kernels through lt_spconv_bwd_weight)
+        self.update_params = str(update_params).lower()
+        if self.update_params == "norm":
+            self.model = configure_model_norm(model_3d, reset_dropout=True)
+        elif self.update_params == "all":
+            self.model = configure_model_all(model_3d, reset_dropout=True)
+        else:
+            raise IndexError(f"Required update params has not been defined yet: {update_params}")   # the reference's error
         self.ema_model = create_ema_model(self.model)
         self.hr = HR_Block(**hr_cfg)
         self.cr = CR_Block(reduction="mean", conf_mask=True, ety_weight=True)
-        self.params = _norm_params(self.model)
+        if self.update_params == "norm":
+            self.params = _norm_params(self.model)
+            self._ema_pairs = (_norm_params(self.ema_model), self.params)
+        else:
+            self.params = list(self.model.parameters())
+            self._ema_pairs = (list(self.ema_model.parameters()), self.params)
         assert {id(p) for p in self.params} == {id(p) for p in self.model.parameters() if p.requires_grad}
-        self._ema_pairs = (_norm_params(self.ema_model), self.params)
         # fused_optimizer (default on the GPU): Adam + EMA as one launch over flat buffers; off: torch.optim.Adam and two
         # multi-tensor EMA ops (the A/B and the parity reference of tests/test_gpu_step.py)
         self.fused = bool(fused_optimizer) and self.params[0].is_cuda
         if self.fused:
-            self.optimizer = FlatAdamEMA(self.params, self._ema_pairs[0], lr=lr, ema_alpha=0.99)
+            self.optimizer = FlatAdamEMA(self.params, self._ema_pairs[0], lr=lr, ema_alpha=0.99,
+                                         allow_missing_grads=self.update_params != "norm")
         else:
             self.optimizer = torch.optim.Adam(self.params, lr=lr)
         self.conf_perc = hr_cfg.get("conf_perc") if conf_perc is None else conf_perc
@@ -256,6 +329,9 @@ class LatteStep:
         # all-reduced per layer, so the sharded step computes what ONE GPU would on the whole batch; the BatchNorm
         # parameter gradients are then global sums on every rank and are not all-reduced again
         self.sync_bn = bool(sync_bn) and self.world > 1
+        if self.sync_bn and self.update_params != "norm":
+            raise ValueError("sync_bn makes the BatchNorm gradients global sums; with update_params='all' the other "
+                             "gradients would still need the all-reduce -- not supported together")
         self.timers = None
         self.trace = None
         # input-only, sync-heavy work (index structures, in-FOV tables, HR_Block.geometry) on a side stream: see
@@ -501,7 +577,10 @@ class LatteStep:
             else:
                 self.allreduce_grads()
             self.optimizer.step()
-            update_ema_norm(self.ema_model, self.model, 0.99, self._ema_pairs)
+            if self.update_params == "norm":
+                update_ema_norm(self.ema_model, self.model, 0.99, self._ema_pairs)
+            else:
+                update_ema_all(self.ema_model, self.model, 0.99, self._ema_pairs)
             return
         flat = self.optimizer.gather_grads()
         if self.world > 1 and not self.sync_bn:
@@ -514,6 +593,9 @@ class LatteStep:
             else:
                 torch.distributed.all_reduce(flat, group=self.pg)
         self.optimizer.step(grad_scale=1.0 / self.world)
+        if self.update_params != "norm":
+            from . import functional as LF
+            LF.bump_pack_epoch()   # conv kernels of student and teacher were written by the kernel: re-pack on next use
 
     def _with_sync_bn(self, fn, *args):
         from . import functional as LF

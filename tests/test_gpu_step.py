@@ -8,7 +8,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _setup(name="tiny", cr=0.5):
+def _setup(name="tiny", cr=0.5, **step_kw):
     from latte_amd import synth
     from latte_amd.spvcnn import Net3DSeg
     from latte_amd.tta_step import LatteStep
@@ -22,7 +22,7 @@ def _setup(name="tiny", cr=0.5):
             mod.weight.data = 0.5 + torch.rand(mod.weight.shape, generator=g)
             mod.bias.data = 0.2 * torch.randn(mod.bias.shape, generator=g)
     model = model.cuda()
-    step = LatteStep(model, w["C"], hr_cfg_of(w))
+    step = LatteStep(model, w["C"], hr_cfg_of(w), **step_kw)
     batch = build_batch(w, device="cuda")
     return w, step, batch
 
@@ -144,6 +144,37 @@ def test_fused_adam_ema_matches_torch_adam_and_ema_update():
         oa.gather_grads()
 
 
+def test_fused_optimizer_state_round_trip():
+    """state_dict / load_state_dict of FlatAdamEMA: a resumed optimizer continues bit-identically."""
+    from latte_amd.tta_step import FlatAdamEMA
+    g = torch.Generator().manual_seed(3)
+    shapes = [(32,), (96,), (5,)]
+    init = [torch.randn(s, generator=g).cuda() for s in shapes]
+    grads = [[torch.randn(s, generator=g).cuda() for s in shapes] for _ in range(4)]
+
+    def run(opt, params, which):
+        for gs in which:
+            for p, gr in zip(params, gs):
+                p.grad = gr.clone()
+            opt.gather_grads()
+            opt.step()
+
+    a = [torch.nn.Parameter(t.clone()) for t in init]
+    oa = FlatAdamEMA(a, None, lr=2e-3)
+    run(oa, a, grads[:2])
+    state = oa.state_dict()
+    b = [torch.nn.Parameter(p.detach().clone()) for p in a]
+    ob = FlatAdamEMA(b, None)
+    ob.load_state_dict(state)
+    assert ob.steps == 2 and ob.lr == 2e-3
+    run(oa, a, grads[2:])
+    run(ob, b, grads[2:])
+    for p, q in zip(a, b):
+        assert torch.equal(p, q)
+    with pytest.raises(ValueError):
+        FlatAdamEMA([torch.nn.Parameter(torch.zeros(3).cuda())], None).load_state_dict(state)
+
+
 def test_fused_and_unfused_update_give_the_same_step():
     """One whole TTA step with the fused update (flat buffers, lt_adam_ema_step) against torch.optim.Adam + update_ema_norm:
     student and teacher parameters agree to 1 ulp-scale after the step.  (Later steps are not comparable element-wise:
@@ -176,3 +207,58 @@ def test_fused_and_unfused_update_give_the_same_step():
             assert ka == kb and torch.allclose(va, vb, rtol=1e-5, atol=3e-7), ka
     for k in l2_f:                                           # and the next iteration sees the same model
         assert abs(l2_f[k] - l2_u[k]) <= 1e-3 * abs(l2_u[k]), (k, l2_f, l2_u)
+
+
+def test_update_params_all_trains_every_parameter():
+    """TRAIN.UPDATE_PARAMS == "all" (latte/tta/tta.py:134-136, ema_util.py:44-71,137-149): every parameter of the student
+    trains -- conv kernels through lt_spconv_bwd_weight -- and the teacher follows with the EMA over every parameter.
+    Gradients of conv kernels (3^3, 2^3 stride 2, transposed, 1^3, the 4-channel stem), point-branch linears and the heads
+    against the oracle's autograd; after the step the packed MFMA images of the changed kernels are rebuilt."""
+    import copy
+    from latte_amd.workload import hr_cfg_of
+    from oracle import step_ref
+    with pytest.raises(IndexError):
+        _setup(update_params="some")
+    w, step, batch = _setup(update_params="all")
+    assert all(p.requires_grad for p in step.model.parameters())
+    assert not any(p.requires_grad for p in step.ema_model.parameters())
+    sd_s = {k: v.detach().cpu() for k, v in step.model.state_dict().items()}
+    sd_t = {k: v.detach().cpu() for k, v in step.ema_model.state_dict().items()}
+    names = ["stem.0.kernel", "stem.3.kernel", "stage1.0.net.0.kernel", "stage2.1.net.0.kernel", "stage2.1.downsample.0.kernel",
+             "stage4.2.net.3.kernel", "up1.0.net.0.kernel", "up1.1.0.net.0.kernel", "up4.1.1.net.3.kernel",
+             "point_transforms.0.0.weight", "point_transforms.2.0.weight", "stem.1.weight", "up4.1.1.net.4.bias"]
+    # (a Linear bias in front of a batch-statistics BatchNorm has a mathematically zero gradient: rounding noise on both
+    # sides, not compared)
+    got = {k: float(v) for k, v in step.forward_backward(batch).items()}
+    lidar = batch["lidar"]
+    want, grads, _, _ = step_ref.tta_step_ref(
+        sd_s, sd_t, lidar.C.cpu().numpy(), lidar.F.cpu(), [i.cpu().numpy() for i in batch["inverse_map"]],
+        [int(i.shape[0]) for i in batch["indices"]], [p.cpu() for p in batch["ori_points"]],
+        [m.cpu() for m in batch["pc2img_idx"]], [p.numpy() for p in batch["pose"]], batch["scene_name"], batch["scan_ID"],
+        batch["logit_2d_student"].detach().cpu(), batch["logit_2d_teacher"].cpu(), hr_cfg_of(w), grad_names=names)
+    for k in ("hr_23", "hr_32", "pl_2d", "pl_3d"):
+        assert abs(got[k] - want[k]) < 2e-3 * abs(want[k]), (k, got[k], want[k])
+    params = dict(step.model.named_parameters())
+    errs = {n: float((params["net_3d." + n].grad.cpu().double() - grads[n].double()).norm() / (grads[n].double().norm() + 1e-12))
+            for n in names}
+    # whole-network gradients: the ReLU-flip bound of test_gpu_spvcnn.py (median 1e-2, worst 5e-2)
+    srt = sorted(errs.values())
+    assert srt[len(srt) // 2] < 1e-2 and srt[-1] < 5e-2, errs
+    # one whole step: every parameter moves, the teacher is the EMA of every parameter
+    step.optimizer.zero_grad()
+    before = {k: v.detach().clone() for k, v in step.model.named_parameters()}
+    ema_before = {k: v.detach().clone() for k, v in step.ema_model.named_parameters()}
+    losses = step.step(batch)
+    assert all(np.isfinite(float(v)) for v in losses.values())
+    after = dict(step.model.named_parameters())
+    unchanged = [k for k in before if torch.equal(before[k], after[k].detach())]
+    assert all(k.startswith("linear2.") for k in unchanged), unchanged[:5]   # the second head is outside the Latte losses
+    for k, e in step.ema_model.named_parameters():
+        assert torch.allclose(e, 0.99 * ema_before[k] + 0.01 * after[k].detach(), rtol=1e-5, atol=1e-7), k
+    # the forward after the update uses the updated kernels: a fresh copy of the model (empty packed-weight caches) agrees
+    fresh = copy.deepcopy(step.model)
+    with torch.no_grad():
+        a = step.model(batch)["seg_logit"]
+        b = fresh(batch)["seg_logit"]
+    assert torch.equal(a, b)
+    step.close()

@@ -20,6 +20,9 @@ def main():
     ap.add_argument("--channels", type=int, default=256)
     ap.add_argument("--code", type=int, default=1244)
     ap.add_argument("--dbg", type=int, default=4)
+    ap.add_argument("--points", type=int, default=34816)
+    ap.add_argument("--beams", type=int, default=32)
+    ap.add_argument("--front", action="store_true")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -32,7 +35,7 @@ def main():
     dev = torch.device("cuda", 0)
     coords = []
     for b in range(args.scans):
-        p, i = synth.make_scan(34816, b, beams=32, full_360=True)
+        p, i = synth.make_scan(args.points, b, beams=args.beams, full_360=not args.front)
         c, f, _, _ = quantize_scan_gpu(torch.from_numpy(p).to(dev), torch.from_numpy(i).to(dev))
         coords.append(torch.cat([c, torch.full((c.shape[0], 1), b, dtype=torch.int32, device=dev)], 1))
     C4 = torch.cat(coords, 0)
