@@ -22,6 +22,7 @@
 #include <hip/hip_ext.h>
 #include <stdlib.h>
 #include "common.h"
+#include <cstdlib>
 #include "../../include/latte_hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -1168,6 +1169,7 @@ static void launch_sj_one(const PlanArgs& a, hipStream_t stream) {
 
 // split-j launch: sr in {1,2,4}, ntw in {2,3,4}, w in {2,3,4,6,8}; needs (Cin/16) % w == 0
 static bool sj_supported(int Cin, int sr, int ntw, int w) {
+  if (ntw == 6) return (sr == 1 || sr == 2) && (w == 2 || w == 3) && (Cin / 16) % w == 0;  // 96 columns per wave
   return (sr == 1 || sr == 2 || sr == 4) && (ntw == 2 || ntw == 3 || ntw == 4) &&
          (w == 2 || w == 3 || w == 4 || w == 6 || w == 8) && (Cin / 16) % w == 0;
 }
@@ -1188,7 +1190,10 @@ static int launch_sj(const PlanArgs& a, int sr, int ntw, int w, hipStream_t stre
     else if (ntw == 3) LT_SJ_W(SRv, 3);                             \
     else LT_SJ_W(SRv, 2);                                           \
   } while (0)
-  if (sr == 4) LT_SJ_NTW(4);
+  if (ntw == 6) {  // one column group of 96: every gathered row is read once
+    if (sr == 2) { if (w == 3) launch_sj_one<2, 6, 3>(a, stream); else launch_sj_one<2, 6, 2>(a, stream); }
+    else { if (w == 3) launch_sj_one<1, 6, 3>(a, stream); else launch_sj_one<1, 6, 2>(a, stream); }
+  } else if (sr == 4) LT_SJ_NTW(4);
   else if (sr == 2) LT_SJ_NTW(2);
   else LT_SJ_NTW(1);
 #undef LT_SJ_NTW
@@ -1566,7 +1571,18 @@ extern "C" int64_t lt_conv_timer_end(float* ms, int32_t* meta, int64_t capacity)
 // precision (k_spconv_bf) for every conv whose effective Cin is a multiple of 32 and at least 64; the caller packs the
 // weights of exactly those convs with mode 4..6 (lt_conv_uses_bf16 is the rule, for both sides).
 static int g_conv_precision = 0;
-static int conv_default_sr(int64_t Vout) { return g_conv_precision ? 2 : (Vout >= 100000 ? 2 : 1); }
+static int64_t conv_sr2_rows() {  // rows from which two strips per wave pay (LATTE_DIAG_CONV_SR2_ROWS: A/B measurements)
+  static const int64_t v = [] {
+    const char* e = getenv("LATTE_DIAG_CONV_SR2_ROWS");
+    return e ? (int64_t)atoll(e) : (int64_t)100000;
+  }();
+  return v;
+}
+static int conv_default_sr(int64_t Vout, int Cout) {
+  (void)Cout;
+  if (g_conv_precision) return 2;
+  return Vout >= conv_sr2_rows() ? 2 : 1;
+}
 static bool conv_uses_bf16(int Cin, int Cout) {
   return g_conv_precision == 1 && Cin >= 64 && Cin % 32 == 0 && Cout >= 32 && Cout % 16 == 0;
 }
@@ -1587,7 +1603,7 @@ static LtConvShape conv_default_shape(int64_t Vin, int64_t Vout, int Cin, int Co
   const int ntt = Cout / 16, J = Cin / 16;
   LtConvShape s;
   s.ntw = ntt % 4 == 0 ? 4 : ntt % 3 == 0 ? 3 : ntt % 2 == 0 ? 2 : 1;
-  s.sr = conv_default_sr(Vout);
+  s.sr = conv_default_sr(Vout, Cout);
   const int64_t waves2 = ((Vout + 16 * s.sr - 1) / (16 * s.sr)) * (ntt / s.ntw) * 2;
   s.w = (waves2 >= 7000 && J < 16) ? 2 : 4;
   if (J % s.w != 0 && J % 2 == 0) s.w = 2;
@@ -1603,7 +1619,7 @@ static int64_t rf_grid_x(int64_t Vout, int sr) {
 
 extern "C" int64_t lt_spconv_stat_blocks(int64_t Vout, int32_t Cout) {
   if (Vout <= 0 || Cout < 16) return 0;
-  return rf_grid_x(Vout, conv_default_sr(Vout));
+  return rf_grid_x(Vout, conv_default_sr(Vout, Cout));
 }
 
 extern "C" int64_t lt_spconv_stats_bytes(int64_t Vout, int32_t Cout) {
