@@ -241,12 +241,56 @@ extern "C" int lt_kmap_reverse(const int32_t* results, int32_t K, int64_t Vout, 
 // issued row-offsets useful; sorting the rows by their K-bit neighbour mask puts rows with the same offsets into the
 // same strip (85-95 % useful).  Stable sort: equal masks keep ascending row order.
 __global__ void k_row_masks(const int* __restrict__ table, int K, int64_t V, unsigned int* __restrict__ masks,
-                            int* __restrict__ iota) {
-  for (int64_t o = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; o < V; o += (int64_t)gridDim.x * blockDim.x) {
+                            int* __restrict__ iota, unsigned int* __restrict__ counts) {
+  __shared__ unsigned int s_cnt[32];
+  if (threadIdx.x < 32) s_cnt[threadIdx.x] = 0u;
+  __syncthreads();
+  for (int64_t o0 = blockIdx.x * (int64_t)blockDim.x; o0 < V; o0 += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t o = o0 + threadIdx.x;
     unsigned int m = 0;
-    for (int k = 0; k < K; ++k) m |= (table[(int64_t)k * V + o] >= 0 ? 1u : 0u) << k;
-    masks[o] = m;
-    iota[o] = (int)o;
+    if (o < V) {
+      for (int k = 0; k < K; ++k) m |= (table[(int64_t)k * V + o] >= 0 ? 1u : 0u) << k;
+      masks[o] = m;
+      iota[o] = (int)o;
+    }
+    // rows per offset (integer atomics: the totals do not depend on the order of the adds)
+    for (int k = 0; k < K; ++k) {
+      const unsigned long long b = __ballot((m >> k) & 1u);
+      if ((threadIdx.x & 63) == 0 && b) atomicAdd(&s_cnt[k], (unsigned int)__popcll(b));
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < K && s_cnt[threadIdx.x]) atomicAdd(&counts[threadIdx.x], s_cnt[threadIdx.x]);
+}
+
+// Sort key of a row: its neighbour mask with the bits permuted so that the offsets FEWEST rows have are the most
+// significant, then Gray-decoded.  Rows that differ only in a common offset end up next to each other, and walking the
+// sorted list changes one high bit at a time -- fewer strips whose union of offsets is larger than each row's own set:
+// 0.885 -> 0.914 useful MFMA rows at stride 1 (3 x 131 072-point scans), 0.815 -> 0.846 on 360-degree scans, against
+// the plain integer order of the masks.  Only the grouping changes: every output row is still accumulated in the
+// same (offset, channel group) order.
+__global__ void k_mask_keys(const unsigned int* masks, const unsigned int* __restrict__ counts, int K, int64_t V,
+                            unsigned int* keys) {  // keys may be masks (in place)
+  __shared__ int s_pos[32];  // s_pos[k] = bit position of offset k in the key
+  if (threadIdx.x < 32) {
+    const int k = threadIdx.x;
+    if (k < K) {
+      const unsigned int ck = counts[k];
+      int rank = 0;  // number of offsets that come before k in descending-count order (ties: lower k first)
+      for (int j = 0; j < K; ++j) {
+        const unsigned int cj = counts[j];
+        rank += (cj > ck || (cj == ck && j < k)) ? 1 : 0;
+      }
+      s_pos[k] = rank;  // the most common offset gets bit 0
+    }
+  }
+  __syncthreads();
+  for (int64_t o = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; o < V; o += (int64_t)gridDim.x * blockDim.x) {
+    const unsigned int m = masks[o];
+    unsigned int g = 0;
+    for (int k = 0; k < K; ++k) g |= ((m >> k) & 1u) << s_pos[k];
+    g ^= g >> 1; g ^= g >> 2; g ^= g >> 4; g ^= g >> 8; g ^= g >> 16;  // rank of g in the reflected Gray code
+    keys[o] = g;
   }
 }
 
@@ -260,7 +304,7 @@ static int64_t order_sort_bytes(int64_t n) {
 
 extern "C" int64_t lt_kmap_order_workspace_bytes(int64_t V) {
   if (V < 1) V = 1;
-  return 3 * lt_align_up(V * 4, 256) + lt_align_up(order_sort_bytes(V), 256) + 1024;
+  return 3 * lt_align_up(V * 4, 256) + lt_align_up(order_sort_bytes(V), 256) + 1024 + 256;
 }
 
 extern "C" int lt_kmap_order(const int32_t* table, int32_t K, int64_t V, void* ws, int64_t ws_bytes, int32_t* order,
@@ -276,7 +320,13 @@ extern "C" int lt_kmap_order(const int32_t* table, int32_t K, int64_t V, void* w
   const int64_t sb = order_sort_bytes(V);
   void* tmp = a.take(sb);
   LT_REQUIRE(masks && smasks && iota && tmp, LT_ERR_WORKSPACE, "lt_kmap_order: arena exhausted");
-  hipLaunchKernelGGL(k_row_masks, dim3(lt_grid(V, 256)), dim3(256), 0, stream, table, K, V, masks, iota);
+  unsigned int* counts = (unsigned int*)a.take(32 * 4);
+  LT_REQUIRE(counts, LT_ERR_WORKSPACE, "lt_kmap_order: arena exhausted");
+  LT_CHECK_HIP(hipMemsetAsync(counts, 0, 32 * 4, stream));
+  hipLaunchKernelGGL(k_row_masks, dim3(lt_grid(V, 256)), dim3(256), 0, stream, table, K, V, masks, iota, counts);
+  LT_LAUNCH_CHECK();
+  // the sort key replaces the mask in place (the masks themselves are not needed again)
+  hipLaunchKernelGGL(k_mask_keys, dim3(lt_grid(V, 256)), dim3(256), 0, stream, masks, counts, K, V, masks);
   LT_LAUNCH_CHECK();
   size_t sbs = (size_t)sb;
   LT_CHECK_HIP(rocprim::radix_sort_pairs<LtSortConfig>(tmp, sbs, masks, smasks, iota, order, (size_t)V, 0, (unsigned)K, stream));

@@ -157,6 +157,8 @@ def test_spconv_order_permutation_is_result_invariant(scans_small):
 
 @pytest.mark.parametrize("ks,stride", [(3, 1), (2, 2)])
 def test_kmap_order_is_stable_mask_sort(scans_small, ks, stride):
+    """lt_kmap_order = stable sort of the rows by a key of their neighbour mask: bits permuted so that the most common
+    offset is bit 0 (ties: lower offset first), then the rank of that word in the reflected Gray code."""
     from latte_amd import ops
     c = scans_small["coords"]
     _, _, out_coords, res = ts_ref.build_kmap(c, 1, ks, stride)
@@ -164,10 +166,24 @@ def test_kmap_order_is_stable_mask_sort(scans_small, ks, stride):
     for table in (resd, ops.kmap_reverse(resd, c.shape[0])):
         t = table.cpu().numpy()
         K = t.shape[0]
-        mask = ((t >= 0).astype(np.int64) << np.arange(K)[:, None]).sum(0)
-        want = np.argsort(mask, kind="stable")
+        act = t >= 0
+        counts = act.sum(1)
+        pos = np.empty(K, dtype=np.int64)
+        pos[np.lexsort((np.arange(K), -counts))] = np.arange(K)   # descending count, ties by offset
+        key = (act.astype(np.int64) << pos[:, None]).sum(0)
+        for sh in (1, 2, 4, 8, 16):
+            key ^= key >> sh
+        want = np.argsort(key, kind="stable")
         got = ops.kmap_order(table).cpu().numpy()
         assert np.array_equal(got, want)
+        # what the order is for: useful fraction of the issued 16-row strip x offset MFMA work, against the plain mask order
+        def useful(order):
+            a = act[:, order]
+            pad = (-a.shape[1]) % 16
+            a = np.concatenate([a, np.zeros((K, pad), dtype=bool)], 1).reshape(K, -1, 16)
+            return act.sum() / (a.any(2).sum() * 16)
+        mask = (act.astype(np.int64) << np.arange(K)[:, None]).sum(0)
+        assert useful(got) >= useful(np.argsort(mask, kind="stable")) - 0.01
     # the order never changes a result bit
     g = torch.Generator().manual_seed(9)
     feats = torch.randn(c.shape[0], 32, generator=g).cuda()
