@@ -67,6 +67,7 @@ def parse():
     ap.add_argument("--conv-precision", default="f32", choices=["f32", "bf16x3"], help="arithmetic of the sparse convs: fp32 "
                     "MFMA (default, the headline) or the opt-in bf16x3 split-precision kernel (lt_conv_set_precision)")
     ap.add_argument("--no-bf16x3-line", action="store_true", help="skip the extra bf16x3 measurement of the default run")
+    ap.add_argument("--no-weak-line", action="store_true", help="N > 1: skip the weak-scaling run of the N = 1 headline workload")
     ap.add_argument("--no-scaling-base", action="store_true", help="N > 1: skip rank 0's one-GPU run of the whole 64-scan step")
     ap.add_argument("--emulate-shard", type=int, default=0, help="diagnostic, one GPU: time the step of rank 0's shard of "
                     "multiseq_64 split over this many ranks (what one rank of an N-GPU run computes; no collective)")
@@ -493,6 +494,21 @@ def main():
     r = time_steps(step, batch, args, world, dev, backend, fwd_only=args.fwd_only, kernel_events=not args.no_kernel_events)
     dt = r["dt"]
 
+    # N > 1, default workload: after the strong-scaling run every rank also times the N = 1 headline workload on its own 6
+    # scans (weak scaling: value / (N x the one-GPU headline) is the efficiency against the driver's N = 1 line)
+    weak = None
+    if world > 1 and args.workload is None and not args.no_weak_line and not args.fwd_only:
+        ww = synth.workload("a2d2_kitti_128k")
+        torch.manual_seed(1)
+        wm = Net3DSeg(ww["C"], True, "SPVCNN", {"cr": args.cr}).to(dev)
+        wstep = LatteStep(wm, ww["C"], hr_cfg_of(ww), process_group=pg, side_stream=not args.no_side_stream)
+        wb = build_batch(ww, device=dev, scan_offset=shard_scan_offset(rank, ww["B"]), seed=rank)
+        wr = time_steps(wstep, wb, args, world, dev, backend, steps=max(5, args.steps // 2), warmup=2, kernel_events=False)
+        weak = {"workload": "a2d2_kitti_128k", "scaling": "weak", "scans_per_gpu": ww["B"], "n_gpus": world,
+                "value": world * ww["B"] * ww["n"] * wr["steps"] / wr["dt"], "unit": "points/s",
+                "ms_per_step": round(1e3 * wr["dt"] / wr["steps"], 3), "steps": wr["steps"]}
+        del wm, wstep, wb
+
     if rank == 0:
         roof = None
         if not args.no_kernel_events:
@@ -551,7 +567,7 @@ def main():
             m1 = Net3DSeg(w["C"], True, "SPVCNN", {"cr": args.cr}).to(dev)
             s1 = LatteStep(m1, w["C"], hr_cfg_of(w), side_stream=not args.no_side_stream)
             b1 = build_batch(w, device=dev, scan_offset=0, seed=0)
-            r1 = time_steps(s1, b1, args, 1, dev, backend, steps=max(3, args.steps // 3), warmup=1, kernel_events=False)
+            r1 = time_steps(s1, b1, args, 1, dev, backend, steps=max(4, args.steps // 2), warmup=2, kernel_events=False)
             base1 = {"n_gpus": 1, "workload": name, "ms_per_step": round(1e3 * r1["dt"] / r1["steps"], 3),
                      "value": n_points_total * r1["steps"] / r1["dt"], "unit": "points/s", "steps": r1["steps"],
                      "speedup_of_this_run": round((r1["dt"] / r1["steps"]) / (dt / args.steps), 3)}
@@ -581,6 +597,8 @@ def main():
             out["bf16x3_mode"] = bf
         if base1 is not None:
             out["strong_scaling_base_measured"] = base1
+        if weak is not None:
+            out["weak_scaling_a2d2"] = weak
         out["config"]["conv_precision"] = args.conv_precision
         if args.emulate_shard > 1 and world == 1:
             out["metric"] = f"DIAGNOSTIC: one rank's shard of multiseq_64 over {args.emulate_shard} ranks, timed alone on one GPU"
