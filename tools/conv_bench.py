@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--stride", type=int, default=1, help="tensor stride of the level the conv runs on (1,2,4,8,16)")
     ap.add_argument("--order", default="auto", help="row processing order: auto (library default) | none | mask | morton")
     ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--storage", default="asis", choices=["asis", "morton", "lex", "random"],
+                    help="storage order of the rows of the level (asis: what the network has)")
     ap.add_argument("--beams", type=int, default=32)
     ap.add_argument("--front", action="store_true", help="front-only +-45 degree scans (KITTI / A2D2 like) instead of 360 degrees")
     ap.add_argument("--out", default=None)
@@ -58,6 +60,24 @@ def main():
         nx.cmaps, nx.kmaps = x.cmaps, x.kmaps
         nx.cmaps[nx.stride] = oc
         x, s = nx, 2 * s
+    if args.storage != "asis":
+        # storage order of the level's rows: the network keeps the reference's order (ascending FNV hash at stride 1);
+        # morton / lex: what a spatially coherent internal order would give the gathers
+        c = x.coords.long()
+        q = c[:, :3] // max(args.stride, 1)
+        if args.storage == "morton":
+            def sp(v):
+                out = torch.zeros_like(v)
+                for b in range(12):
+                    out |= ((v >> b) & 1) << (3 * b)
+                return out
+            key = (c[:, 3] << 40) | (sp(q[:, 0]) << 2) | (sp(q[:, 1]) << 1) | sp(q[:, 2])
+        elif args.storage == "lex":
+            key = (c[:, 3] << 48) | (q[:, 0] << 32) | (q[:, 1] << 16) | q[:, 2]
+        else:  # random
+            key = torch.randperm(c.shape[0], device=c.device)
+        perm = torch.argsort(key, stable=True)
+        x = SparseTensor(torch.zeros(c.shape[0], 4, device=dev), x.coords[perm].contiguous(), x.stride)
     kmap, _ = spnn.build_kernel_map(x, 3, 1, 1)
     nbr = kmap.results
     V = nbr.shape[1]
