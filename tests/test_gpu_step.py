@@ -262,3 +262,21 @@ def test_update_params_all_trains_every_parameter():
         b = fresh(batch)["seg_logit"]
     assert torch.equal(a, b)
     step.close()
+
+
+def test_rotating_batches_with_prefetch_stay_finite():
+    """A short soak (tools/soak.py): 9 iterations over three different batches, each announced one iteration ahead
+    (prefetch on the side stream + helper thread), no host sync between iterations; every loss and parameter stays finite."""
+    from latte_amd.workload import build_batch
+    w, step, b0 = _setup()
+    batches = [b0] + [build_batch(w, device="cuda", scan_offset=50 * i, seed=i) for i in (1, 2)]
+    out = []
+    for i in range(9):
+        nb = batches[(i + 1) % 3] if i < 8 else None
+        out.append(step.step(batches[i % 3], next_batch=nb))
+    step.close()
+    torch.cuda.synchronize()
+    for losses in out:
+        assert all(np.isfinite(float(v)) for v in losses.values())
+    for (n, p), (_, e) in zip(step.model.named_parameters(), step.ema_model.named_parameters()):
+        assert torch.isfinite(p).all() and torch.isfinite(e).all(), n
