@@ -64,13 +64,14 @@ def make_pose(j: int) -> np.ndarray:
 
 # BASELINE.json configs restated as synthetic workloads.
 WORKLOADS = {
-    # name: n_points, n_scans(B), classes, temp_wd_size, voxel_size, max_range, full_360, beams, frames/sequence
-    "synthia_kitti_32k_b1": dict(n=32768, B=1, C=9, W=3, vs=0.2, R=40, full_360=False, beams=64, seq_len=1),
-    "synthia_kitti_32k": dict(n=32768, B=6, C=9, W=3, vs=0.2, R=40, full_360=False, beams=64, seq_len=6),
-    "nuscenes_34k_w5": dict(n=34816, B=6, C=16, W=5, vs=0.2, R=50, full_360=True, beams=32, seq_len=6),
-    "a2d2_kitti_128k": dict(n=131072, B=6, C=10, W=3, vs=0.1, R=40, full_360=False, beams=64, seq_len=6),
-    "multiseq_64": dict(n=34816, B=64, C=16, W=5, vs=0.2, R=50, full_360=True, beams=32, seq_len=8),
-    "tiny": dict(n=2048, B=3, C=5, W=3, vs=0.4, R=30, full_360=False, beams=16, seq_len=3),
+    # name: n_points, n_scans(B), classes, temp_wd_size, voxel_size, max_range, full_360, beams, frames/sequence,
+    # conf = HR_BLOCK.conf_perc of the matching configs/*/latte.yaml:29 (0.9 for the two KITTI targets, 0.5 for nuScenes)
+    "synthia_kitti_32k_b1": dict(n=32768, B=1, C=9, W=3, vs=0.2, R=40, full_360=False, beams=64, seq_len=1, conf=0.9),
+    "synthia_kitti_32k": dict(n=32768, B=6, C=9, W=3, vs=0.2, R=40, full_360=False, beams=64, seq_len=6, conf=0.9),
+    "nuscenes_34k_w5": dict(n=34816, B=6, C=16, W=5, vs=0.2, R=50, full_360=True, beams=32, seq_len=6, conf=0.5),
+    "a2d2_kitti_128k": dict(n=131072, B=6, C=10, W=3, vs=0.1, R=40, full_360=False, beams=64, seq_len=6, conf=0.9),
+    "multiseq_64": dict(n=34816, B=64, C=16, W=5, vs=0.2, R=50, full_360=True, beams=32, seq_len=8, conf=0.5),
+    "tiny": dict(n=2048, B=3, C=5, W=3, vs=0.4, R=30, full_360=False, beams=16, seq_len=3, conf=0.9),
 }
 
 

@@ -27,30 +27,39 @@ __all__ = ["configure_model_norm", "configure_model_all", "create_ema_model", "u
            "LatteStep", "FlatAdamEMA", "shard_scan_offset", "shard_sequences", "allreduce_mean_grads"]
 
 
-def configure_model_norm(model: nn.Module, reset_dropout: bool = True):
-    """ema_util.configure_model_norm: train mode, only *norm* modules trainable, BN on batch statistics."""
+def configure_model_norm(model: nn.Module, reset_dropout: bool = True) -> list:
+    """ema_util.configure_model_norm (:6-41): train mode, only *norm* modules trainable, BN on batch statistics.
+    -> [model, [norm module names, [dropout module names]]] -- the reference's return value, which its callers unpack as
+    `model, _ = configure_model_norm(...)` (latte/tta/tta.py:130-136); the inner list nesting is the reference's own."""
     model.train()
     model.requires_grad_(False)
-    for _, m in model.named_modules():
+    norm_list, dropout_modules = [], []
+    for mod_name, m in model.named_modules():
         name = type(m).__name__.lower()
         if "norm" in name:
             m.requires_grad_(True)
+            norm_list.append(mod_name)
             if "batchnorm" in name:
                 m.track_running_stats = False
                 m.running_mean = None
                 m.running_var = None
         elif reset_dropout and "dropout" in name:
             m.p = 0.0
-    return model
+            dropout_modules.append(mod_name)
+    out = [model, [norm_list]]
+    if reset_dropout:
+        out[1].append([dropout_modules])
+    return out
 
 
-def configure_model_all(model: nn.Module, reset_dropout: bool = True):
-    """ema_util.configure_model_all (TRAIN.UPDATE_PARAMS == "all"): train mode, EVERY parameter trainable (the reference
-    walks named_modules and enables grad on every module that is neither norm nor dropout -- the root module included),
-    BatchNorm on batch statistics, dropout reset on request."""
+def configure_model_all(model: nn.Module, reset_dropout: bool = True) -> list:
+    """ema_util.configure_model_all (:44-71, TRAIN.UPDATE_PARAMS == "all"): train mode, EVERY parameter trainable (the
+    reference walks named_modules and enables grad on every module that is neither norm nor dropout -- the root module
+    included), BatchNorm on batch statistics, dropout reset on request.  -> [model, [dropout module names]]"""
     model.train()
     model.requires_grad_(False)
-    for _, m in model.named_modules():
+    dropout_modules = []
+    for mod_name, m in model.named_modules():
         name = type(m).__name__.lower()
         if "norm" in name:
             m.requires_grad_(True)
@@ -59,19 +68,23 @@ def configure_model_all(model: nn.Module, reset_dropout: bool = True):
             m.running_var = None
         elif reset_dropout and "dropout" in name:
             m.p = 0.0
+            dropout_modules.append(mod_name)
         else:
             m.requires_grad_(True)
-    return model
+    return [model, [dropout_modules]]
 
 
-def create_ema_model(model: nn.Module) -> nn.Module:
+def create_ema_model(model: nn.Module) -> list:
+    """ema_util.create_ema_model (:74-96): a detached deep copy with dropout off.  -> [ema_model, [dropout module names]]"""
     ema = deepcopy(model)
     for p in ema.parameters():
         p.detach_()
-    for _, m in ema.named_modules():
+    dropout_modules = []
+    for mod_name, m in ema.named_modules():
         if "dropout" in type(m).__name__.lower():
             m.p = 0.0
-    return ema
+            dropout_modules.append(mod_name)
+    return [ema, [dropout_modules]]
 
 
 def _norm_params(model: nn.Module) -> List[torch.Tensor]:
@@ -83,21 +96,26 @@ def _norm_params(model: nn.Module) -> List[torch.Tensor]:
 
 
 @torch.no_grad()
-def update_ema_norm(ema_model: nn.Module, model: nn.Module, alpha: float = 0.99, params=None) -> nn.Module:
-    """ema = alpha*ema + (1-alpha)*student on the norm parameters (ema_util.update_ema_norm), as two multi-tensor ops.
+def update_ema_norm(ema_model: nn.Module, model: nn.Module, alpha_teacher: float = 0.99, iteration=None, params=None) -> nn.Module:
+    """ema = alpha*ema + (1-alpha)*student on the norm parameters (ema_util.update_ema_norm :99-118, same argument names
+    and the same warm-up rule for `iteration`), as two multi-tensor ops.
     params: (ema list, student list) collected once by the caller (walking both module trees costs 1.2 ms per step)."""
+    if iteration:
+        alpha_teacher = min(1 - 1 / (iteration + 1), alpha_teacher)
     e, s = params if params is not None else (_norm_params(ema_model), _norm_params(model))
-    torch._foreach_mul_(e, alpha)
-    torch._foreach_add_(e, s, alpha=1.0 - alpha)
+    torch._foreach_mul_(e, alpha_teacher)
+    torch._foreach_add_(e, s, alpha=1.0 - alpha_teacher)
     return ema_model
 
 
 @torch.no_grad()
-def update_ema_all(ema_model: nn.Module, model: nn.Module, alpha: float = 0.99, params=None) -> nn.Module:
-    """ema = alpha*ema + (1-alpha)*student on EVERY parameter (ema_util.update_ema_all, TRAIN.UPDATE_PARAMS == "all")."""
+def update_ema_all(ema_model: nn.Module, model: nn.Module, alpha_teacher: float = 0.99, iteration=None, params=None) -> nn.Module:
+    """ema = alpha*ema + (1-alpha)*student on EVERY parameter (ema_util.update_ema_all :137-149, TRAIN.UPDATE_PARAMS == "all")."""
+    if iteration:
+        alpha_teacher = min(1 - 1 / (iteration + 1), alpha_teacher)
     e, s = params if params is not None else (list(ema_model.parameters()), list(model.parameters()))
-    torch._foreach_mul_(e, alpha)
-    torch._foreach_add_(e, s, alpha=1.0 - alpha)
+    torch._foreach_mul_(e, alpha_teacher)
+    torch._foreach_add_(e, s, alpha=1.0 - alpha_teacher)
     from . import functional as LF
     LF.bump_pack_epoch()   # the teacher's conv kernels changed: their packed MFMA images are stale
     return ema_model
@@ -296,12 +314,12 @@ class LatteStep:
         # norm layers' gamma / beta train) or "all" (every parameter trains: conv kernels through lt_spconv_bwd_weight)
         self.update_params = str(update_params).lower()
         if self.update_params == "norm":
-            self.model = configure_model_norm(model_3d, reset_dropout=True)
+            self.model, _ = configure_model_norm(model_3d, reset_dropout=True)
         elif self.update_params == "all":
-            self.model = configure_model_all(model_3d, reset_dropout=True)
+            self.model, _ = configure_model_all(model_3d, reset_dropout=True)
         else:
             raise IndexError(f"Required update params has not been defined yet: {update_params}")   # the reference's error
-        self.ema_model = create_ema_model(self.model)
+        self.ema_model, _ = create_ema_model(self.model)
         self.hr = HR_Block(**hr_cfg)
         self.cr = CR_Block(reduction="mean", conf_mask=True, ety_weight=True)
         if self.update_params == "norm":
@@ -334,6 +352,7 @@ class LatteStep:
                              "gradients would still need the all-reduce -- not supported together")
         self.timers = None
         self.trace = None
+        self.debug_out = None   # tests: when a dict, forward_backward leaves its discrete decisions (pseudo labels, masks) in it
         # input-only, sync-heavy work (index structures, in-FOV tables, HR_Block.geometry) on a side stream: see
         # forward_backward
         self.hr_side_stream = side_stream
@@ -561,6 +580,8 @@ class LatteStep:
         loss_2d.append(pl2)
         loss_3d.append(pl3)
         self._tick("cr_ce")
+        if self.debug_out is not None:
+            self.debug_out.update(ps_label=ps_label, conf_mask_23=hr23["tr_conf_mask"], conf_mask_32=hr32["tr_conf_mask"])
         (sum(loss_3d) + sum(loss_2d)).backward()
         self._tick("backward")
         return {"hr_23": l23.detach(), "hr_32": l32.detach(), "pl_2d": pl2.detach(), "pl_3d": pl3.detach()}
@@ -578,9 +599,9 @@ class LatteStep:
                 self.allreduce_grads()
             self.optimizer.step()
             if self.update_params == "norm":
-                update_ema_norm(self.ema_model, self.model, 0.99, self._ema_pairs)
+                update_ema_norm(self.ema_model, self.model, 0.99, params=self._ema_pairs)
             else:
-                update_ema_all(self.ema_model, self.model, 0.99, self._ema_pairs)
+                update_ema_all(self.ema_model, self.model, 0.99, params=self._ema_pairs)
             return
         flat = self.optimizer.gather_grads()
         if self.world > 1 and not self.sync_bn:

@@ -16,7 +16,8 @@ __all__ = ["build_batch", "hr_cfg_of", "build_conv_1m"]
 
 
 def hr_cfg_of(w: Dict) -> Dict:
-    return dict(temp_wd_size=w["W"], max_range=w["R"], voxel_size=w["vs"], conf_perc=0.9)
+    """HR_BLOCK knobs of a workload (latte/config/xmuda.py:293-298); conf_perc is the dataset's own value"""
+    return dict(temp_wd_size=w["W"], max_range=w["R"], voxel_size=w["vs"], conf_perc=w.get("conf", 0.9))
 
 
 def build_batch(w: Dict, device="cuda", scan_offset: int = 0, seed: int = 0) -> Dict:

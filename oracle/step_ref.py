@@ -68,10 +68,17 @@ def pseudo_label_fuse_ref(logit_2d_teacher: torch.Tensor, logit_3d_teacher: torc
 def tta_step_ref(student_sd: Dict, teacher_sd: Dict, coords: np.ndarray, feats: torch.Tensor, inverse_maps, sizes,
                  ori_points: List[torch.Tensor], fov_masks: List[torch.Tensor], poses, scene_names, scan_ids,
                  logit_2d_student: torch.Tensor, logit_2d_teacher: torch.Tensor, hr_cfg: Dict,
-                 lambda_hr_23: float = 0.3, lambda_hr_32: float = 0.3, grad_names=None, backward: bool = True):
-    """-> (losses dict, {param name: grad} for `grad_names`, grad of logit_2d_student)."""
+                 lambda_hr_23: float = 0.3, lambda_hr_32: float = 0.3, grad_names=None, backward: bool = True,
+                 student_relu_masks=None, ps_label_override=None, conf_mask_override=None):
+    """-> (losses dict, {param name: grad} for `grad_names`, grad of logit_2d_student, aux).
+
+    The three *_override arguments fix the step's DISCRETE decisions from outside (tests/test_gpu_step.py feeds the GPU
+    run's): the student's ReLU activity pattern (see SPVCNNRef.relu_masks), the pseudo labels after refine, and the two
+    tr_conf_masks (hr_23, hr_32).  An activation / label / entropy that is tied to fp32 rounding may fall on either side
+    in two correct implementations; with the decisions shared, what is left to compare is arithmetic."""
     teacher = SPVCNNRef(teacher_sd)
     student = SPVCNNRef(student_sd)
+    student.relu_masks = student_relu_masks
     params = student.parameters_requiring_grad(grad_names) if grad_names else []
     l2s = logit_2d_student.detach().clone().requires_grad_(True)
     extra = dict(pose=poses, scene_name=scene_names, scan_ID=scan_ids,
@@ -93,6 +100,12 @@ def tta_step_ref(student_sd: Dict, teacher_sd: Dict, coords: np.ndarray, feats: 
         pc2, pc3, ps_prob = pseudo_label_fuse_ref(logit_2d_teacher, ema3d, mask, hr32["hs_pc_ety"], hr23["hs_pc_ety"],
                                                   hr_cfg["conf_perc"])
         ps_label = hr_ref.refine_pseudo_labels(ps_prob.amax(1), ps_prob.argmax(1))
+    ps_label_own = ps_label
+    if ps_label_override is not None:
+        ps_label = ps_label_override.to(ps_label.dtype)
+    own_masks = (hr23["tr_conf_mask"], hr32["tr_conf_mask"])
+    if conf_mask_override is not None:
+        hr23["tr_conf_mask"], hr32["tr_conf_mask"] = conf_mask_override
     hr23.update({"ac_pc_ety": pc2, "tr_pc_ety": pc3})
     l23 = hr_ref.cr_forward(hr23)
     hr32.update({"ac_pc_ety": pc3, "tr_pc_ety": pc2})
@@ -105,4 +118,5 @@ def tta_step_ref(student_sd: Dict, teacher_sd: Dict, coords: np.ndarray, feats: 
         total.backward()
         grads = {n: p.grad for n, p in zip(grad_names or [], params)}
     losses = {"hr_23": float(l23.detach()), "hr_32": float(l32.detach()), "pl_2d": float(pl2.detach()), "pl_3d": float(pl3.detach())}
-    return losses, grads, (l2s.grad if backward else None), {"ps_label": ps_label, "hr23": hr23, "hr32": hr32}
+    return losses, grads, (l2s.grad if backward else None), {"ps_label": ps_label_own, "hr23": hr23, "hr32": hr32,
+                                                                   "conf_masks": own_masks, "student": student}

@@ -53,7 +53,7 @@ from latte.data.utils.refine_pseudo_labels import refine_ety, refine_pseudo_labe
 from latte_amd import synth  # noqa: E402
 
 
-def make_case(name, n, B, C, W, vs, R, beams, full_360, seq_len, seed):
+def make_case(name, n, B, C, W, vs, R, beams, full_360, seq_len, seed, conf=0.75):
     g = torch.Generator().manual_seed(seed)
     pts, poses, scenes, ids, fov = [], [], [], [], []
     for b in range(B):
@@ -78,7 +78,7 @@ def make_case(name, n, B, C, W, vs, R, beams, full_360, seq_len, seed):
     common = dict(pose=poses, scene_name=scenes, scan_ID=ids, img_indices=[torch.zeros(f.shape[0], 2) for f in fov])
     b3 = lambda lg: dict(seg_logit=lg, ori_points=pts, **common)
     b2 = lambda lg: dict(seg_logit=lg, ori_points=pts_2d, **common)
-    hr = HR_Block(temp_wd_size=W, max_range=R, voxel_size=vs, conf_perc=0.75)
+    hr = HR_Block(temp_wd_size=W, max_range=R, voxel_size=vs, conf_perc=conf)
     cr = CR_Block(reduction="mean", conf_mask=True, ety_weight=True)
     out = {}
     for tag, (ab, at, hb, ht, a_lg) in {
@@ -124,7 +124,7 @@ def make_case(name, n, B, C, W, vs, R, beams, full_360, seq_len, seed):
     out["in_logit_3d_teacher"] = logit_3d_teacher.numpy()
     out["in_logit_2d_student"] = logit_2d_student.detach().numpy()
     out["in_logit_2d_teacher"] = logit_2d_teacher.numpy()
-    out["cfg"] = np.array([n, B, C, W, vs, R, 0.75], dtype=np.float64)
+    out["cfg"] = np.array([n, B, C, W, vs, R, conf], dtype=np.float64)
     np.savez_compressed(os.path.join(HERE, f"hr_{name}.npz"), **out)
     print(name, "saved;", {k: v.shape for k, v in out.items() if k.startswith("23_ac_logits")},
           "loss23", out["23_cr_loss"], "loss32", out["32_cr_loss"])
@@ -136,6 +136,11 @@ CASES = {
     "w5_360": dict(n=3072, B=5, C=16, W=5, vs=0.2, R=50, beams=32, full_360=True, seq_len=5, seed=2),
     # BASELINE configs[2] (A2D2 -> SemanticKITTI: latte/config/xmuda.py:293-298 knobs vs 0.1, R 40, W 3; 10 classes, B 6)
     "a2d2": dict(n=4096, B=6, C=10, W=3, vs=0.1, R=40, beams=64, full_360=False, seq_len=6, seed=3),
+    # BASELINE configs[0] at its own shape: ONE 32 768-point scan (B = 1: a single anchor whose window is itself), the
+    # Synthia -> SemanticKITTI knobs of configs/synthia_semantic_kitti/latte.yaml:26-29 (W 3, R 40, vs 0.2, conf_perc 0.9)
+    "b1_32k": dict(n=32768, B=1, C=9, W=3, vs=0.2, R=40, beams=64, full_360=False, seq_len=1, seed=4, conf=0.9),
+    # nuScenes USA -> Singapore knobs (configs/nuscenes/usa_singapore/latte.yaml:26-29): W 3, R 50, vs 0.2, conf_perc 0.5
+    "nusc_cp05": dict(n=3072, B=6, C=16, W=3, vs=0.2, R=50, beams=32, full_360=True, seq_len=6, seed=5, conf=0.5),
 }
 
 if __name__ == "__main__":

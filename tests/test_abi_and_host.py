@@ -117,3 +117,48 @@ def test_cross_entropy_matches_torch():
         gb, = torch.autograd.grad(b, x)
         assert abs(float(a) - float(b)) < 1e-6 * abs(float(b))
         assert float((ga - gb).abs().max()) < 1e-7
+
+
+def test_ema_util_mirrors_return_what_the_reference_returns():
+    """configure_model_norm / configure_model_all / create_ema_model / update_ema_* of latte_amd.tta_step against the values
+    the reference's own latte/common/utils/ema_util.py produced on the same module tree (tests/golden/ema_util_returns.json,
+    made by tests/golden/make_ema_util_golden.py): the nested [model, [lists]] return value its callers unpack
+    (latte/tta/tta.py:130-136), the trainable set, dropout, the BatchNorm statistics mode, the EMA warm-up rule."""
+    import json
+    import os
+    from latte_amd.spvcnn import Net3DSeg
+    from latte_amd import tta_step as T
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ema_util_returns.json")))
+
+    def net():
+        torch.manual_seed(0)
+        return Net3DSeg(9, True, "SPVCNN", {"cr": 0.5})
+
+    def describe(model):
+        return {"trainable": sorted(n for n, p in model.named_parameters() if p.requires_grad),
+                "training": bool(model.training),
+                "dropout_p": {n: float(m.p) for n, m in model.named_modules() if "dropout" in type(m).__name__.lower()},
+                "bn_track": sorted(n for n, m in model.named_modules()
+                                   if "batchnorm" in type(m).__name__.lower() and m.track_running_stats)}
+
+    for reset in (True, False):
+        for fn in ("configure_model_norm", "configure_model_all"):
+            r = getattr(T, fn)(net(), reset)
+            want = gold[f"{fn}_{reset}"]
+            assert isinstance(r, list) and len(r) == 2 and isinstance(r[0], torch.nn.Module)
+            assert r[1] == want["lists"], fn
+            assert describe(r[0]) == want["model"], fn
+    model, _ = T.configure_model_norm(net(), True)          # how the reference's callers unpack it
+    r = T.create_ema_model(model)
+    assert r[1] == gold["create_ema_model"]["lists"] and describe(r[0]) == gold["create_ema_model"]["model"]
+    assert any(p.requires_grad for p in r[0].parameters()) == gold["create_ema_model"]["requires_grad_any"]
+    for fn in ("update_ema_norm", "update_ema_all"):
+        for it in (None, 3):
+            s, e = net(), net()
+            with torch.no_grad():
+                for p in s.parameters():
+                    p.add_(1.0)
+            getattr(T, fn)(e, s, 0.99, it)
+            ref = net()
+            for (n, pe), (_, pr) in zip(e.named_parameters(), ref.named_parameters()):
+                assert abs(float((pe - pr).abs().max()) - gold[f"{fn}_{it}"]["moved"][n]) < 1e-5, (fn, it, n)

@@ -1,4 +1,4 @@
-"""BASELINE.json configs[2], [3], [4] on the GPU at their full sizes, through size-independent properties (the CPU oracle is
+"""BASELINE.json configs[0] (against the CPU oracle at its own size) and configs[2], [3], [4] on the GPU at their full sizes, through size-independent properties (the CPU oracle is
 too slow to be the checker there; small-size oracle parity of the same code is in test_gpu_ops / _spvcnn / _stvoxel / _step):
 
   configs[2]  A2D2 -> SemanticKITTI: 6 x 131 072-point scans, 5 cm input voxels, ST voxels 0.1 m, R 40 m, 10 classes
@@ -18,6 +18,93 @@ def _x0_of(lidar):
     from latte_amd.tensor import PointTensor
     z = PointTensor(lidar.F, lidar.C.float())
     return initial_voxelize(z, 0.05, 0.05), z
+
+
+# ---------------------------------------------------------------------------------------------------- configs[0]
+def test_config0_one_32k_scan_step_matches_oracle():
+    """BASELINE configs[0] at its own shape: ONE synthetic 32 768-point scan (B = 1), Synthia -> SemanticKITTI knobs
+    (configs/synthia_semantic_kitti/latte.yaml: 9 classes, W 3, R 40, vs 0.2, conf_perc 0.9), SPVCNN cr = 1.0 -- the
+    configuration BASELINE.json names as the CPU-reference case, so the CPU oracle is the checker at full size: every
+    index structure of the backbone bit-exact, logits and the four losses of the whole TTA iteration to 1e-3.  B = 1 is its
+    own code path: a single anchor whose window is itself (Wmax = 1), one anchor bit in the ST keys.  (The ST-voxel half
+    of this shape is also pinned to the reference's own code: tests/golden/hr_b1_32k.npz in test_gpu_stvoxel.py.)"""
+    from latte_amd import sparse_modules as spnn
+    from latte_amd import synth
+    from latte_amd.point_voxel import initial_voxelize
+    from latte_amd.spvcnn import Net3DSeg
+    from latte_amd.tensor import PointTensor, SparseTensor
+    from latte_amd.tta_step import LatteStep
+    from latte_amd.workload import build_batch, hr_cfg_of
+    from oracle import step_ref
+    from oracle.spvcnn_ref import SPVCNNRef
+    w = synth.workload("synthia_kitti_32k_b1")
+    assert w["B"] == 1 and w["n"] == 32768 and w["C"] == 9 and w["conf"] == 0.9
+    torch.manual_seed(1)
+    model = Net3DSeg(w["C"], True, "SPVCNN", {"cr": 1.0})
+    g = torch.Generator().manual_seed(2)
+    for mod in model.modules():
+        if isinstance(mod, torch.nn.BatchNorm1d):
+            mod.weight.data = 0.5 + torch.rand(mod.weight.shape, generator=g)
+            mod.bias.data = 0.2 * torch.randn(mod.bias.shape, generator=g)
+    step = LatteStep(model.cuda(), w["C"], hr_cfg_of(w))
+    batch = build_batch(w, device="cuda")
+    lidar = batch["lidar"]
+    assert len(batch["ori_points"]) == 1 and batch["ori_points"][0].shape[0] == 32768 and int(lidar.C[:, 3].max()) == 0
+    coords = lidar.C.cpu().numpy()
+
+    # ---- the backbone's index structures against the oracle, every level
+    sd_t = {k: v.detach().cpu() for k, v in step.ema_model.state_dict().items()}
+    ref = SPVCNNRef(sd_t)
+    with torch.no_grad():
+        want = ref(coords, lidar.F.cpu())
+        got = step.ema_model(batch)
+    z = PointTensor(lidar.F, lidar.C.float())
+    t = initial_voxelize(z, 0.05, 0.05)
+    assert np.array_equal(t.C.cpu().numpy(), ref.traced["x0_coords"])
+    assert np.array_equal(z.additional_features["idx_query"][1].cpu().numpy(), ref.traced["idx_query_1"])
+    for lvl, name in zip((1, 2, 4, 8, 16), ("x1", "x2", "x3", "x4", None)):
+        km3, _ = spnn.build_kernel_map(t, 3, 1, 1)
+        nb, ns, _, _ = ref.traced["kmaps"][(lvl, 3, 1)]
+        assert np.array_equal(km3[0].cpu().numpy(), nb) and np.array_equal(km3[1].cpu().numpy(), ns), lvl
+        if name is None:
+            break
+        km2, oc = spnn.build_kernel_map(t, 2, 2, 1)
+        nb, ns, _, want_oc = ref.traced["kmaps"][(lvl, 2, 2)]
+        assert np.array_equal(oc.cpu().numpy(), want_oc) and np.array_equal(oc.cpu().numpy(), ref.traced[name + "_coords"])
+        assert np.array_equal(km2[0].cpu().numpy(), nb) and np.array_equal(km2[1].cpu().numpy(), ns), lvl
+        nt = SparseTensor(torch.zeros(oc.shape[0], 4, device="cuda"), oc, 2 * lvl)
+        nt.cmaps, nt.kmaps = t.cmaps, t.kmaps
+        nt.cmaps[nt.stride] = oc
+        t = nt
+    for k in ("feats", "seg_logit", "seg_logit2"):
+        a, b = got[k].cpu().double(), want[k].double()
+        assert float((a - b).norm() / b.norm()) < 1e-4, k
+        assert torch.allclose(got[k].cpu(), want[k], rtol=1e-3, atol=1e-3 * float(want[k].abs().max())), k
+
+    # ---- the whole iteration against the oracle's
+    sd_s = {k: v.detach().cpu() for k, v in step.model.state_dict().items()}
+    losses = {k: float(v) for k, v in step.forward_backward(batch).items()}
+    want_l, _, g2d, aux = step_ref.tta_step_ref(
+        sd_s, sd_t, coords, lidar.F.cpu(), [i.cpu().numpy() for i in batch["inverse_map"]],
+        [int(i.shape[0]) for i in batch["indices"]], [p.cpu() for p in batch["ori_points"]],
+        [m.cpu() for m in batch["pc2img_idx"]], [p.numpy() for p in batch["pose"]], batch["scene_name"], batch["scan_ID"],
+        batch["logit_2d_student"].detach().cpu(), batch["logit_2d_teacher"].cpu(), hr_cfg_of(w))
+    for k in ("hr_23", "hr_32"):
+        assert abs(losses[k] - want_l[k]) < 1e-3 * abs(want_l[k]), (k, losses[k], want_l[k])
+    for k in ("pl_2d", "pl_3d"):   # discrete pseudo labels: a flipped label moves the loss by ~1/N
+        assert abs(losses[k] - want_l[k]) < 2e-3 * abs(want_l[k]), (k, losses[k], want_l[k])
+    g = batch["logit_2d_student"].grad.cpu()
+    assert float((g - g2d).norm() / g2d.norm()) < 2e-3
+    # the single anchor matched voxels on both HR calls, and the ST entropy reached every in-range point
+    assert all(len(aux[h]["ac_logits"]) == 1 and aux[h]["ac_logits"][0].shape[0] > 1000 for h in ("hr23", "hr32"))
+    # ---- and it steps: prefetch one iteration ahead, parameters move, everything finite
+    batch["logit_2d_student"].grad = None
+    before = [p.detach().clone() for p in step.params]
+    l1 = step.step(batch, next_batch=batch)
+    l2 = step.step(batch)
+    step.close()
+    assert all(np.isfinite(float(v)) for l in (l1, l2) for v in l.values())
+    assert any(not torch.equal(a, b.detach()) for a, b in zip(before, step.params))
 
 
 # ---------------------------------------------------------------------------------------------------- configs[2]

@@ -55,6 +55,68 @@ def test_tta_iteration_matches_oracle():
     assert errs[len(errs) // 2] < 1e-2, errs[len(errs) // 2]
 
 
+def test_tta_iteration_gradients_match_oracle_to_1e3_under_shared_decisions():
+    """The step-level gradient bar at 1e-3 (north_star), median AND worst, instead of the free-running 1e-2 above.
+
+    A TTA iteration takes discrete decisions on values that can be tied to fp32 rounding: the sign of every ReLU input of
+    the student, the arg-max / median filter behind every pseudo label, the class-quantile side of every ST-voxel entropy.
+    Two correct implementations may fall on different sides of a handful of them, and one flip moves every gradient below
+    it by ~1/sqrt(elements).  Here (1) the decisions of the GPU run and of the free-running oracle are compared and must
+    differ only on a vanishing fraction, and (2) the oracle is re-run taking the GPU run's decisions: every BatchNorm
+    gradient of the student and the gradient of the 2-D student logits then match within 1e-3."""
+    import latte_amd.spvcnn as spv
+    from latte_amd.workload import hr_cfg_of
+    from oracle import step_ref
+    w, step, batch = _setup()
+    sd_s = {k: v.detach().cpu() for k, v in step.model.state_dict().items()}
+    sd_t = {k: v.detach().cpu() for k, v in step.ema_model.state_dict().items()}
+    names = [f"{mn}.{pn}"[len("net_3d."):] for mn, mod in step.model.named_modules()
+             if isinstance(mod, torch.nn.BatchNorm1d) and mn.startswith("net_3d.") for pn, _ in mod.named_parameters()]
+    step.debug_out = {}
+    spv.ACT_TRACE = {}
+    try:
+        got = {k: float(v) for k, v in step.forward_backward(batch).items()}
+    finally:
+        trace, spv.ACT_TRACE = spv.ACT_TRACE, None
+    name_of = {id(mod): mn[len("net_3d."):] for mn, mod in step.model.named_modules() if mn.startswith("net_3d.")}
+    gpu_act = {name_of[k]: v.cpu() for k, v in trace.items() if k in name_of}      # the student's (the teacher has its own ids)
+    dbg = step.debug_out
+    lidar = batch["lidar"]
+    args = (sd_s, sd_t, lidar.C.cpu().numpy(), lidar.F.cpu(), [i.cpu().numpy() for i in batch["inverse_map"]],
+            [int(i.shape[0]) for i in batch["indices"]], [p.cpu() for p in batch["ori_points"]],
+            [m.cpu() for m in batch["pc2img_idx"]], [p.numpy() for p in batch["pose"]], batch["scene_name"], batch["scan_ID"],
+            batch["logit_2d_student"].detach().cpu(), batch["logit_2d_teacher"].cpu(), hr_cfg_of(w))
+    # (1) the free-running oracle's decisions against the GPU run's
+    _, _, _, aux = step_ref.tta_step_ref(*args, backward=False)
+    ps_gpu = dbg["ps_label"].cpu().long()
+    assert float((aux["ps_label"].long() != ps_gpu).float().mean()) <= 2e-3
+    for own, mine in zip(aux["conf_masks"], (dbg["conf_mask_23"], dbg["conf_mask_32"])):
+        assert own.shape == mine.shape and int((own != mine.cpu()).sum()) <= 2
+    pre = aux["student"].pre
+    assert set(pre.keys()) <= set(gpu_act.keys())
+    total = flips = 0
+    for n, x in pre.items():
+        differ = (x > 0) != (gpu_act[n] > 0)
+        total += x.numel()
+        flips += int(differ.sum())
+        if differ.any():
+            assert float(x[differ].abs().max()) <= 1e-4 * float(x.abs().max()), n
+    assert flips <= 1e-5 * total, (flips, total)
+    # (2) the oracle under the GPU run's decisions
+    want, grads, g2d, _ = step_ref.tta_step_ref(*args, grad_names=names, student_relu_masks={n: gpu_act[n] > 0 for n in pre},
+                                                ps_label_override=ps_gpu,
+                                                conf_mask_override=(dbg["conf_mask_23"].cpu(), dbg["conf_mask_32"].cpu()))
+    for k in ("hr_23", "hr_32", "pl_2d", "pl_3d"):
+        assert abs(got[k] - want[k]) < 1e-3 * abs(want[k]), (k, got[k], want[k])
+    g = batch["logit_2d_student"].grad.cpu()
+    assert float((g - g2d).norm() / g2d.norm()) < 1e-3
+    params = dict(step.model.named_parameters())
+    errs = sorted((float((params["net_3d." + n].grad.cpu().double() - grads[n].double()).norm() /
+                         (grads[n].double().norm() + 1e-12)), n) for n in names)
+    print("step BN-grad rel errs under shared decisions: median", errs[len(errs) // 2][0], "worst", errs[-1])
+    assert errs[len(errs) // 2][0] < 1e-3 and errs[-1][0] < 1e-3, errs[-4:]
+
+
 def test_step_updates_norm_parameters_only_and_ema_follows():
     w, step, batch = _setup()
     before = {k: v.detach().clone() for k, v in step.model.state_dict().items()}

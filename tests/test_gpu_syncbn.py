@@ -46,7 +46,7 @@ def _model(dev):
         if isinstance(mod, torch.nn.BatchNorm1d):
             mod.weight.data = 0.5 + torch.rand(mod.weight.shape, generator=g)
             mod.bias.data = 0.2 * torch.randn(mod.bias.shape, generator=g)
-    return configure_model_norm(m.to(dev))
+    return configure_model_norm(m.to(dev))[0]
 
 
 def _point_weights(scan_ids):
