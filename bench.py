@@ -62,6 +62,8 @@ def parse():
                     "HR geometry) on the main stream too")
     ap.add_argument("--no-prefetch", action="store_true", help="build the index structures of a batch inside its own step "
                     "instead of one step ahead")
+    ap.add_argument("--no-from-raw", action="store_true", help="skip the extra measurement whose timed region starts at raw "
+                    "host points (H2D + input voxelization + collate on the side stream, one step ahead)")
     ap.add_argument("--dump-conv", default=None, help="write the per-launch conv table of one step (JSON) here")
     ap.add_argument("--fwd-only", action="store_true", help="time teacher forward only")
     ap.add_argument("--conv-precision", default="f32", choices=["f32", "bf16x3"], help="arithmetic of the sparse convs: fp32 "
@@ -99,8 +101,8 @@ def _cpu_leg(w, cr, n_scans, threads, seed=1):
     g = torch.Generator().manual_seed(0)
     l2s = 3 * torch.randn(n_fov, w["C"], generator=g)
     l2t = 3 * torch.randn(n_fov, w["C"], generator=g)
-    t0 = time.perf_counter()
-    coords, feats, invs, sizes = step_ref.quantize_batch(scans)
+    coords, feats, invs, sizes = step_ref.quantize_batch(scans)   # outside the timer, like the GPU step's `value` (inputs
+    t0 = time.perf_counter()                                      # already voxelized; `from_raw` times it on the GPU side)
     step_ref.tta_step_ref(sd, sd, coords, torch.from_numpy(feats), invs, sizes, ori, fov,
                           [synth.make_pose(j) for j in range(n_scans)], ["scene-1000"] * n_scans, list(range(n_scans)),
                           l2s, l2t, hr_cfg_of(w), grad_names=names)
@@ -112,7 +114,7 @@ def _cpu_leg(w, cr, n_scans, threads, seed=1):
 def cpu_baseline(w, cr, n_scans=None):
     """Two legs on the same bounded sample: all cores the box gives this process, and the reference's OMP_NUM_THREADS=4."""
     import torch
-    all_cores = int(torch.get_num_threads())
+    all_cores = int(os.environ.get("LATTE_BENCH_CPU_THREADS", 0)) or int(torch.get_num_threads())
     if n_scans is None:
         # the step's whole batch when that is <= ~1 M points (measured on the GPU box: ~40 k points/s on 16 threads, ~34 k on
         # 4 -> ~20 s + ~24 s for the 6 x 131 072-point batch), else as many whole scans as fit 1 M points
@@ -120,7 +122,7 @@ def cpu_baseline(w, cr, n_scans=None):
     full = _cpu_leg(w, cr, n_scans, all_cores)
     omp4 = _cpu_leg(w, cr, n_scans, min(4, all_cores))
     torch.set_num_threads(all_cores)
-    sample = (f"one oracle TTA step (oracle/step_ref.py: quantize, teacher fwd, student fwd, 2x HR, 2x CR, CE, backward) on "
+    sample = (f"one oracle TTA step (oracle/step_ref.py: teacher fwd, student fwd, 2x HR, 2x CR, CE, backward; inputs already voxelized) on "
               f"{n_scans} scan(s) x {w['n']} points of the same workload (the step's batch is {w['B']} scans), torch-CPU "
               f"fp32: {full['seconds']} s with {all_cores} threads, {omp4['seconds']} s with {omp4['cores']} threads "
               f"(the reference pins OMP_NUM_THREADS=4); the reference's own backend (torchsparse v1.4.0 CUDA) cannot run here")
@@ -199,8 +201,10 @@ def hbm_classes(batch, w, hr):
     out = {}
 
     def add(name, us, nbytes, what):
+        # the fraction is of the 8 TB/s HBM spec, but each class is timed in a loop over ONE working set of 2..700 MB that
+        # stays resident in the 256 MB Infinity Cache between repetitions: a cache-resident rate, not a cold HBM rate
         out[name] = {"us": round(us, 1), "bytes": int(nbytes), "GBs": round(nbytes / us / 1e3, 1),
-                     "frac_hbm": round(nbytes / us / 1e3 / PEAK_HBM_GBS, 4), "what": what}
+                     "frac_of_8TBs_cache_resident": round(nbytes / us / 1e3 / PEAK_HBM_GBS, 4), "what": what}
 
     # hash + unique (initial_voxelize: FNV hash of every point, sorted unique hashes, point -> voxel inverse)
     ci = lidar.C.int().contiguous()
@@ -454,7 +458,19 @@ def main():
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # stream creation order of a rank, the same in every run: main (the null stream), the side stream, then whatever the
+    # process group creates (main + side + collective stream = 3 <= 4 hardware queues)
+    from latte_amd.tta_step import ensure_side_stream
+    ensure_side_stream(dev)
     pg = None
+    # LATTE_BENCH_FORCE_PG=1 (one rank): a one-rank nccl group whose all-reduce is issued every step -- the stream and thread
+    # topology of an N-rank run (collective stream, watchdog thread) rehearsed on a one-GPU box
+    force_pg = world == 1 and bool(os.environ.get("LATTE_BENCH_FORCE_PG"))
+    if force_pg:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(backend, rank=0, world_size=1, **({"device_id": dev} if backend == "nccl" else {}))
+        pg = dist.group.WORLD
     if world > 1:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -487,7 +503,7 @@ def main():
     torch.manual_seed(1)  # cfg.RNG_SEED (latte/common/config/base.py:173); same weights on every rank
     model = Net3DSeg(w["C"], True, "SPVCNN", {"cr": args.cr}).to(dev)
     step = LatteStep(model, w["C"], hr_cfg_of(w), process_group=pg, side_stream=not args.no_side_stream,
-                     sync_bn=args.sync_bn)
+                     sync_bn=args.sync_bn, force_collective=force_pg)
     batch = build_batch(w_rank, device=dev, scan_offset=scan_offset, seed=rank)
     n_points_total = total_scans * w["n"]
 
@@ -529,7 +545,7 @@ def main():
         others = None
         if world == 1 and args.workload is None and not args.no_other_workloads and not args.fwd_only:
             others = {}
-            for oname in ("nuscenes_34k_w5", "synthia_kitti_32k"):
+            for oname in ("nuscenes_34k_w5", "synthia_kitti_32k", "synthia_kitti_32k_b1"):
                 ow = synth.workload(oname)
                 torch.manual_seed(1)
                 om = Net3DSeg(ow["C"], True, "SPVCNN", {"cr": args.cr}).to(dev)
@@ -541,6 +557,11 @@ def main():
                                  "ms_per_step": round(1e3 * orr["dt"] / orr["steps"], 3), "steps": orr["steps"],
                                  "points_per_step": ob["n_points"], "voxels": ob["n_voxels"],
                                  "conv_tflops": oroof["achieved"], "conv_frac_mfma": oroof["frac"]}
+                if oname == "synthia_kitti_32k_b1" and not args.no_cpu_baseline:
+                    # BASELINE configs[0] is THE CPU-reference configuration (one 32 768-point scan): the oracle's step on
+                    # exactly that input, all threads and the reference's OMP_NUM_THREADS = 4
+                    others[oname]["config"] = "BASELINE configs[0]: one synthetic 32k-point scan, B = 1 (the CPU-reference case)"
+                    others[oname]["cpu_baseline"] = cpu_baseline(ow, args.cr, 1)
                 del om, ostep, ob
         bf = None
         if (world == 1 and args.workload is None and args.conv_precision == "f32" and not args.no_bf16x3_line
@@ -559,6 +580,31 @@ def main():
                           "hi*hi + hi*lo + lo*hi accumulated in fp32 (~1e-5 relative to the fp32 kernel); opt-in, never the headline"}
             _ops.set_conv_precision("f32")
             del bm, bstep
+        from_raw = None
+        if world == 1 and not args.no_from_raw and not args.fwd_only and not args.no_side_stream and not args.no_prefetch:
+            # the same step with the timed region starting at RAW host points: per iteration 6 x 131 072 x 16 B over PCIe from
+            # pinned memory + round(p*20)-min + sparse_quantize + collate (semantic_kitti_dataloader.py:542-577,
+            # tools/latte.py:139-148), done by the helper thread on the side stream one iteration ahead of its step
+            from latte_amd.workload import batch_from_raw, make_raw
+            raw = make_raw(w_rank, scan_offset)
+            l2 = (batch["logit_2d_student"], batch["logit_2d_teacher"])
+            factory = lambda: batch_from_raw(raw, w_rank, device=dev, logits_2d=l2)   # noqa: E731
+            step.prefetch(factory)
+            for _ in range(2):
+                step.step(None, next_batch=factory)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step.step(None, next_batch=factory)
+            torch.cuda.synchronize()
+            dt_raw = time.perf_counter() - t0
+            step.close()
+            from_raw = {"value": n_points_total * args.steps / dt_raw, "unit": "points/s",
+                        "ms_per_step": round(1e3 * dt_raw / args.steps, 3), "steps": args.steps,
+                        "h2d_bytes_per_step": int(n_points_total * 16),
+                        "what": "timed region starts at raw host points (pinned): H2D + input voxelization "
+                                "(quantize_scan_gpu) + collate run on the side stream one iteration ahead, then the same step; "
+                                "never the headline `value` (that one starts with the inputs resident in HBM)"}
         base1 = None
         if world > 1 and scaling == "strong" and not args.no_scaling_base:
             # the strong-scaling base in the SAME run: rank 0 alone takes the whole 64-scan step (the other ranks wait at
@@ -595,16 +641,21 @@ def main():
             out["other_workloads"] = others
         if bf is not None:
             out["bf16x3_mode"] = bf
+        if from_raw is not None:
+            out["from_raw"] = from_raw
         if base1 is not None:
             out["strong_scaling_base_measured"] = base1
         if weak is not None:
             out["weak_scaling_a2d2"] = weak
         out["config"]["conv_precision"] = args.conv_precision
+        if force_pg:
+            out["config"]["rehearsal"] = f"one-rank {backend} process group, gradient all-reduce issued every step"
         if args.emulate_shard > 1 and world == 1:
             out["metric"] = f"DIAGNOSTIC: one rank's shard of multiseq_64 over {args.emulate_shard} ranks, timed alone on one GPU"
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()      # ranks > 0 wait here while rank 0 measures the one-GPU base
+    if world > 1 or force_pg:
         dist.destroy_process_group()
 
 

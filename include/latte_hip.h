@@ -13,7 +13,14 @@
  *    through a HOST pointer (those calls synchronise `stream`; they are marked [sync])
  *  - workspaces are opaque byte buffers sized by the matching *_workspace_bytes() query
  *  - feature matrices are row-major fp32 [rows, channels]; coordinates are int32 [rows,4] = (x,y,z,batch)
- *  - one caller thread per device; calls on different devices/streams are independent
+ *  - threads and devices: every entry point is re-entrant -- it keeps no state between calls beyond what the caller passes
+ *    (buffers, workspaces, plans) and launches only on the given stream, on that stream's device -- so calls from
+ *    several threads and on several devices of one process are independent as long as they do not share output or
+ *    workspace buffers (latte_amd's prefetch thread builds index structures on a side stream while the main thread
+ *    launches the convs).  The exceptions are the PROCESS-WIDE switches and diagnostics, to be called while no other
+ *    thread is inside the library: lt_conv_set_precision, lt_conv_timer_begin / _arm / _end (conv launches from any
+ *    thread are recorded while armed; slot hand-out is locked), lt_conv_debug_stamps; and lt_bn_stats_static, whose
+ *    calls share one scratch array per GPU (see there).  lt_last_error() is thread-local.
  */
 #ifndef LATTE_HIP_H
 #define LATTE_HIP_H
@@ -186,9 +193,10 @@ int lt_bn_stats(const float* x, int64_t V, int32_t C, void* ws, int64_t ws_bytes
 /* lt_bn_stats for callers that cannot allocate (HIP graph capture, serving loops, harnesses that forbid hipMalloc): NO
  * counterpart in the reference.  Same kernels and results as lt_bn_stats, but the per-block partial sums live in a
  * file-scope device array of the library (2 MiB per GPU, held until the process ends) instead of a caller workspace;
- * the call allocates nothing.  Limit: C <= 256 (LT_ERR_RANGE beyond it).  The first call on a device looks the array's
- * address up (with that device current, which must be the stream's device).  All calls on one GPU share the array:
- * calls that overlap on one GPU (different streams) race -- serialise them. */
+ * the call allocates nothing.  Limit: C <= 256 (LT_ERR_RANGE beyond it).  The array used is the one of the GPU that
+ * `stream` lives on (hipStreamGetDevice; the null stream: the current device), whatever device is current in the calling
+ * thread: the first call for a device looks its address up with that device current, later calls reuse it.  All calls on
+ * one GPU share the array: calls that overlap on one GPU (different streams or threads) race -- serialise them. */
 int lt_bn_stats_static(const float* x, int64_t V, int32_t C, float* mean, float* var, lt_stream_t stream);
 /* mean / biased variance from the column sums lt_spconv_plan_fwd_stats left in stats_ws (V = Vout, C = Cout of that call) */
 int lt_bn_finalize_sums(void* stats_ws, int64_t V, int32_t C, float* mean, float* var, lt_stream_t stream);

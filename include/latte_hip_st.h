@@ -94,4 +94,23 @@ int lt_pseudo_label_fuse(const float* logits_2d, const float* logits_3d, const i
 int64_t lt_quantile_workspace_bytes(int64_t n);
 int lt_quantile(const float* x, int64_t n, float q, void* ws, int64_t ws_bytes, float* out, lt_stream_t stream);
 
+/* CR_Block.forward (latte/models/hr_module.py:344-420): entropy-weighted KL between matched anchor / hist ST-voxel
+ * distributions.  ac, tr [M,C]: matched voxel PROBABILITIES of all anchors, rows sorted by anchor (anchor_start[B+1], device;
+ * the matched lists are already aligned: the reference's two argsorts :359-360 are the identity, Q3).
+ *   w[m] = exp(-t_e)/(exp(-t_e)+exp(-a_e)), a_e = ac_pc_ety[ac_p2v[m]], t_e = tr_pc_ety[tr_p2v[m]] (:373-377; the four
+ *          pointers NULL together: w = 1, the ety_weight=False / self_corr branch :379-380)
+ *   row_loss[m] = w[m] * sum_c tr~ (log tr~ - log ac~), x~ = x == 0 ? 1e-8 : x   (the clamp on probabilities, :405-410)
+ *   loss[0] = 1/B sum_b mean_{m in anchor b, keep[m]} row_loss[m]                (keep = tr_conf_mask :367-371; NULL: all)
+ * Outputs kept for the backward: row_w [M], anchor_stats [B][2] = (sum, count) of the kept rows.  Two launches, fixed
+ * summation order, no sync.  C <= 64. */
+int lt_cr_loss_fwd(const float* ac, const float* tr, int64_t M, int32_t C, const float* ac_pc_ety, const int64_t* ac_p2v,
+                   const float* tr_pc_ety, const int64_t* tr_p2v, const uint8_t* keep, const int32_t* anchor_start,
+                   int32_t B, float* row_w, float* row_loss, float* anchor_stats, float* loss, lt_stream_t stream);
+/* gradient of loss[0] w.r.t. ac (tr is detached in the reference, :409): g_ac[m,c] = -gloss[0]/B * keep[m] * w[m] /
+ * count_b * tr~[m,c] / ac[m,c], 0 where ac == 0 (the clamp replaced the element by a constant).  row_anchor [M] int64:
+ * anchor of every row; gloss: device scalar. */
+int lt_cr_loss_bwd(const float* ac, const float* tr, int64_t M, int32_t C, const float* row_w, const uint8_t* keep,
+                   const int64_t* row_anchor, const float* anchor_stats, int32_t B, const float* gloss, float* g_ac,
+                   lt_stream_t stream);
+
 #endif

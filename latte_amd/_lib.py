@@ -98,6 +98,8 @@ SIGNATURES = {
     "lt_quantile_workspace_bytes": (I64, [I64]),
     "lt_quantile": (ctypes.c_int, [P, I64, F32, P, I64, P, P]),
     "lt_pseudo_label_fuse": (ctypes.c_int, [P, P, P, P, P, P, P, I64, I64, I32, P, P, P, P, P, P]),
+    "lt_cr_loss_fwd": (ctypes.c_int, [P, P, I64, I32, P, P, P, P, P, P, I32, P, P, P, P, P]),
+    "lt_cr_loss_bwd": (ctypes.c_int, [P, P, I64, I32, P, P, P, P, I32, P, P, P]),
 }
 
 _lib = None

@@ -270,10 +270,34 @@ static __device__ __align__(256) float scratch[(size_t)BN_MAX_BLOCKS * 2 * LT_BN
 static float* g_scratch_ptr[LT_BN_STATIC_MAX_DEVICES];
 static std::mutex g_scratch_mu;
 
-static int bn_static_scratch(float** out) {
-  int dev = -1;
-  LT_CHECK_HIP(hipGetDevice(&dev));
-  LT_REQUIRE(dev >= 0 && dev < LT_BN_STATIC_MAX_DEVICES, LT_ERR_RANGE, "lt_bn_stats_static: device %d out of range", dev);
+// RAII: make `dev` the current device for the scope (lookup + launches), restore the caller's on exit
+struct LtDeviceScope {
+  int prev = -1, dev = -1;
+  bool switched = false;
+  int enter(int d) {
+    dev = d;
+    LT_CHECK_HIP(hipGetDevice(&prev));
+    if (prev != d) {
+      LT_CHECK_HIP(hipSetDevice(d));
+      switched = true;
+    }
+    return LT_OK;
+  }
+  ~LtDeviceScope() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+};
+
+// device that `stream` belongs to (the null stream: the current device)
+static int bn_stream_device(hipStream_t stream, int* dev) {
+  LT_CHECK_HIP(hipGetDevice(dev));
+  if (stream) LT_CHECK_HIP(hipStreamGetDevice(stream, dev));
+  LT_REQUIRE(*dev >= 0 && *dev < LT_BN_STATIC_MAX_DEVICES, LT_ERR_RANGE, "lt_bn_stats_static: device %d out of range", *dev);
+  return LT_OK;
+}
+
+// scratch pointer of device `dev`, looked up once with THAT device current (each GPU holds its own copy of the array)
+static int bn_static_scratch(int dev, float** out) {
   std::lock_guard<std::mutex> lock(g_scratch_mu);
   if (!g_scratch_ptr[dev]) {
     void* p = nullptr;
@@ -292,8 +316,16 @@ extern "C" int lt_bn_stats_static(const float* x, int64_t V, int32_t C, float* m
              "lt_bn_stats_static: C=%d exceeds the built-in scratch (max %d channels); use lt_bn_stats with a workspace", C,
              LT_BN_STATIC_MAX_C);
   LT_REQUIRE(x && mean && var, LT_ERR_ARG, "lt_bn_stats_static: null pointer");
+  // the scratch array of the GPU the STREAM lives on, whatever device is current in the calling thread: lookup and
+  // launches run with that device current (restored on return)
+  int dev = -1;
+  rc = bn_stream_device(stream, &dev);
+  if (rc) return rc;
+  LtDeviceScope scope;
+  rc = scope.enter(dev);
+  if (rc) return rc;
   float* ws = nullptr;
-  rc = bn_static_scratch(&ws);
+  rc = bn_static_scratch(dev, &ws);
   if (rc) return rc;
   const int nb = bn_blocks(V, C);
   const int cg = C / 4, rpi = BN_BLOCK / cg > 0 ? BN_BLOCK / cg : 1;

@@ -21,6 +21,8 @@
 //    in a wave's 16-row strip skip that wave's MFMAs (wave-uniform branch).
 #include <hip/hip_ext.h>
 #include <stdlib.h>
+#include <atomic>
+#include <mutex>
 #include "common.h"
 #include <cstdlib>
 #include "../../include/latte_hip.h"
@@ -299,7 +301,8 @@ struct PlanArgs {
 
 // events of the armed conv launch timer for the launch being issued (null otherwise): the conv kernels are launched
 // with hipExtLaunchKernelGGL, which stamps them with the dispatch's own begin / end times (no extra barrier packets)
-static hipEvent_t g_conv_ev0 = nullptr, g_conv_ev1 = nullptr;
+// thread_local: set by LtConvTimerScope in the thread that issues the launch, read by LT_CONV_LAUNCH in the same thread
+static thread_local hipEvent_t g_conv_ev0 = nullptr, g_conv_ev1 = nullptr;
 #define LT_CONV_LAUNCH(kernel, grid, block, stream, ...) \
   hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, g_conv_ev0, g_conv_ev1, 0, __VA_ARGS__)
 
@@ -1500,7 +1503,8 @@ struct LtConvTimer {
   hipEvent_t* ev = nullptr;  // 2 * cap
   int32_t* meta = nullptr;   // 4 * cap: Cin, Cout, K, Vout
   int cap = 0, n = 0, dropped = 0;
-  bool armed = false;
+  std::atomic<bool> armed{false};
+  std::mutex mu;             // slot hand-out and begin / end: conv launches may come from several threads
 };
 static LtConvTimer g_timer;
 
@@ -1508,7 +1512,9 @@ struct LtConvTimerScope {
   int slot = -1;
   hipStream_t stream;
   LtConvTimerScope(hipStream_t s, int Cin, int Cout, int K, int64_t Vout) : stream(s) {
-    if (!g_timer.armed) return;
+    if (!g_timer.armed.load(std::memory_order_relaxed)) return;
+    std::lock_guard<std::mutex> lock(g_timer.mu);
+    if (!g_timer.armed.load()) return;
     if (g_timer.n >= g_timer.cap) { ++g_timer.dropped; return; }
     slot = g_timer.n++;
     int32_t* m = g_timer.meta + 4 * slot;
@@ -1521,6 +1527,7 @@ struct LtConvTimerScope {
 
 extern "C" int lt_conv_timer_begin(int32_t capacity) {
   LT_REQUIRE(capacity > 0 && capacity <= (1 << 20), LT_ERR_ARG, "lt_conv_timer_begin: capacity %d not in [1, 2^20]", capacity);
+  std::lock_guard<std::mutex> lock(g_timer.mu);
   if (capacity > g_timer.cap) {
     hipEvent_t* ev = (hipEvent_t*)realloc(g_timer.ev, sizeof(hipEvent_t) * 2 * capacity);
     int32_t* meta = (int32_t*)realloc(g_timer.meta, sizeof(int32_t) * 4 * capacity);
@@ -1544,6 +1551,7 @@ extern "C" int lt_conv_timer_arm(int32_t on) {
 
 extern "C" int64_t lt_conv_timer_end(float* ms, int32_t* meta, int64_t capacity) {
   g_timer.armed = false;
+  std::lock_guard<std::mutex> lock(g_timer.mu);
   LT_REQUIRE(g_timer.dropped == 0, LT_ERR_RANGE, "lt_conv_timer_end: %d launches beyond the capacity given to lt_conv_timer_begin",
              g_timer.dropped);
   const int n = g_timer.n;
@@ -1570,7 +1578,7 @@ extern "C" int64_t lt_conv_timer_end(float* ms, int32_t* meta, int64_t capacity)
 // Process-wide arithmetic of the planned conv kernels: 0 = fp32 MFMA (default; bit-reproducible fmaf chains), 1 = bf16x3 split
 // precision (k_spconv_bf) for every conv whose effective Cin is a multiple of 32 and at least 64; the caller packs the
 // weights of exactly those convs with mode 4..6 (lt_conv_uses_bf16 is the rule, for both sides).
-static int g_conv_precision = 0;
+static std::atomic<int> g_conv_precision{0};
 static int64_t conv_sr2_rows() {  // rows from which two strips per wave pay (LATTE_DIAG_CONV_SR2_ROWS: A/B measurements)
   static const int64_t v = [] {
     const char* e = getenv("LATTE_DIAG_CONV_SR2_ROWS");
@@ -1583,8 +1591,15 @@ static int conv_default_sr(int64_t Vout, int Cout) {
   if (g_conv_precision) return 2;
   return Vout >= conv_sr2_rows() ? 2 : 1;
 }
+// ONE rule for the pack side (lt_conv_uses_bf16 -> functional._packed picks mode 4..6) and the launch side: the conv takes
+// the bf16x3 kernel iff this says so.  It includes what the default bf16 shape needs -- a column-tile count per wave
+// (4, 3 or 2) that divides Cout/16 -- so that Cout = 80 or 112 (5 or 7 tiles) stay on the fp32 kernels on BOTH sides.
+static int bf_default_ntw(int Cout) {
+  const int ntt = Cout / 16;
+  return ntt % 4 == 0 ? 4 : ntt % 3 == 0 ? 3 : ntt % 2 == 0 ? 2 : 0;
+}
 static bool conv_uses_bf16(int Cin, int Cout) {
-  return g_conv_precision == 1 && Cin >= 64 && Cin % 32 == 0 && Cout >= 32 && Cout % 16 == 0;
+  return g_conv_precision == 1 && Cin >= 64 && Cin % 32 == 0 && Cout >= 32 && Cout % 16 == 0 && bf_default_ntw(Cout) != 0;
 }
 extern "C" int lt_conv_set_precision(int32_t mode) {
   LT_REQUIRE(mode == 0 || mode == 1, LT_ERR_ARG, "lt_conv_set_precision: mode %d not in {0 (fp32), 1 (bf16x3)}", mode);
@@ -1659,11 +1674,21 @@ static int spconv_plan_impl(const float* in, const float* packed, const void* pl
   LtConvTimerScope timed(stream, Cin, Cout, K, Vout);
   const int ntt = Cout / 16;
   LT_REQUIRE(!(partial && variant != 0), LT_ERR_ARG, "lt_spconv_plan_fwd: statistics need the default variant");
-  if (variant == 0 && conv_uses_bf16(Cin, Cout) && Vin * Cin * 4 < 0x7FFFF000ll && (int64_t)K * Cin * Cout * 4 < 0x7FFFF000ll) {
+  if (conv_uses_bf16(Cin, Cout) && !(variant >= 3000 && variant < 4000)) {
+    // The caller packed this conv's weights as the bf16 hi|lo image (same rule, lt_conv_uses_bf16): only the bf16x3 kernel
+    // may read them.  What it cannot run is an error, never a silent fall-through to an fp32 kernel over a bf16 image.
+    LT_REQUIRE(variant == 0, LT_ERR_ARG,
+               "lt_spconv_plan_fwd_v: variant %d is an fp32 kernel, but under lt_conv_set_precision(1) the weights of a "
+               "Cin=%d Cout=%d conv are packed as the bf16 image (use variant 0 or 3xxx, or precision 0)", variant, Cin, Cout);
+    LT_REQUIRE(Vin * Cin * 4 < 0x7FFFF000ll && (int64_t)K * Cin * Cout * 4 < 0x7FFFF000ll, LT_ERR_RANGE,
+               "lt_spconv_plan_fwd: bf16x3 kernel addresses its operands with 32-bit buffer offsets: Vin*Cin*4 = %lld and "
+               "K*Cin*Cout*4 = %lld must stay below 2 GiB (use lt_conv_set_precision(0) for this size)",
+               (long long)(Vin * Cin * 4), (long long)((int64_t)K * Cin * Cout * 4));
     // bf16x3: 32-row workgroups on every level, channel pair-groups over two waves when their count is even (measured per
     // level at the a2d2 sizes, tools/cb_bf16.py)
-    const int jp = Cin / 32;
-    return launch_bf(a, 2, ntt % 4 == 0 ? 4 : ntt % 3 == 0 ? 3 : 2, jp % 2 == 0 ? 2 : 1, stream);
+    const int jp = Cin / 32, ntw = bf_default_ntw(Cout), w = jp % 2 == 0 ? 2 : 1;
+    LT_REQUIRE(bf_supported(Cin, Cout, 2, ntw, w), LT_ERR_ARG, "lt_spconv_plan_fwd: no bf16x3 shape for Cin=%d Cout=%d", Cin, Cout);
+    return launch_bf(a, 2, ntw, w, stream);
   }
   if (variant == 0) {
     const LtConvShape sh = conv_default_shape(Vin, Vout, Cin, Cout, K);

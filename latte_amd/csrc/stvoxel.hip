@@ -162,13 +162,18 @@ struct HeadFlag {
   }
 };
 
-__global__ void k_iota(int* __restrict__ a, int64_t n) {
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) a[i] = (int)i;
+// flag (optional): cleared here, raised by k_emit_segments (a later launch on the same stream)
+__global__ void k_iota(int* __restrict__ a, int64_t n, int* __restrict__ flag) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    a[i] = (int)i;
+    if (i == 0 && flag) *flag = 0;
+  }
 }
 
 __global__ void k_emit_segments(const int64_t* __restrict__ skeys, const int* __restrict__ selem, const int* __restrict__ vid,
                                 int64_t E, int* __restrict__ inverse, int64_t* __restrict__ uniq, int* __restrict__ seg_start,
-                                int* __restrict__ counts /* [0]=V, [1]=n_valid */) {
+                                int* __restrict__ counts /* [0]=V, [1]=n_valid, [2]=a key broke the key_bits promise */,
+                                unsigned end_bit) {
   for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < E; p += (int64_t)gridDim.x * blockDim.x) {
     const int64_t k = skeys[p];
     const int e = selem[p];
@@ -177,6 +182,8 @@ __global__ void k_emit_segments(const int64_t* __restrict__ skeys, const int* __
       if (p == 0) { counts[0] = 0; counts[1] = 0; seg_start[0] = 0; }
       continue;
     }
+    // an unmasked key with a bit at or above the sorted range: the array is NOT sorted, every result below is garbage
+    if (k < 0 || (end_bit < 63u && (k >> (end_bit - 1u)) != 0)) counts[2] = 1;
     const int v = vid[p] - 1;  // inclusive scan of head flags
     inverse[e] = v;
     if (p == 0 || skeys[p - 1] != k) { uniq[v] = k; seg_start[v] = (int)p; }
@@ -230,7 +237,7 @@ extern "C" int lt_sort_segments(const int64_t* keys, int64_t E, int32_t key_bits
   void* stmp = a.take(sb);
   void* ctmp = a.take(cb);
   LT_REQUIRE(skeys && iota && vid && counts && stmp && ctmp, LT_ERR_WORKSPACE, "lt_sort_segments: arena exhausted");
-  hipLaunchKernelGGL(k_iota, dim3(lt_grid(E, 256)), dim3(256), 0, stream, iota, E);
+  hipLaunchKernelGGL(k_iota, dim3(lt_grid(E, 256)), dim3(256), 0, stream, iota, E, counts + 2);
   LT_LAUNCH_CHECK();
   size_t sbs = (size_t)sb, cbs = (size_t)cb;
   // LSD radix sort is stable: equal keys keep ascending element order => segment head = first occurrence
@@ -238,11 +245,15 @@ extern "C" int lt_sort_segments(const int64_t* keys, int64_t E, int32_t key_bits
   auto it = rocprim::make_transform_iterator(rocprim::counting_iterator<int>(0), HeadFlag{skeys});
   LT_CHECK_HIP(rocprim::inclusive_scan(ctmp, cbs, it, vid, (size_t)E, rocprim::plus<int>(), stream));
   hipLaunchKernelGGL(k_emit_segments, dim3(lt_grid(E, 256)), dim3(256), 0, stream, skeys, sorted_elem, vid, E, inverse,
-                     uniq_keys, seg_start, counts);
+                     uniq_keys, seg_start, counts, end_bit);
   LT_LAUNCH_CHECK();
-  int host[2] = {0, 0};
-  LT_CHECK_HIP(hipMemcpyAsync(host, counts, 8, hipMemcpyDeviceToHost, stream));
+  int host[3] = {0, 0, 0};
+  LT_CHECK_HIP(hipMemcpyAsync(host, counts, 12, hipMemcpyDeviceToHost, stream));
   LT_CHECK_HIP(hipStreamSynchronize(stream));
+  // the promise is checked on the device (one compare per key in a kernel that reads every key anyway): a stale key_bits or
+  // an anchor id beyond its bits would otherwise give a silently mis-sorted array, wrong segments and wrong joins
+  LT_REQUIRE(host[2] == 0, LT_ERR_RANGE, "lt_sort_segments: an unmasked key is negative or >= 2^%d (key_bits = %d): outputs invalid",
+             (int)end_bit - 1, key_bits);
   *V = host[0];
   return LT_OK;
 }
@@ -682,6 +693,137 @@ extern "C" int lt_quantile(const float* x, int64_t n, float q, void* ws, int64_t
   size_t sbs = (size_t)sb;
   LT_CHECK_HIP(rocprim::radix_sort_keys<LtSortConfig>(tmp, sbs, keys, skeys, (size_t)n, 0, 32, stream));
   hipLaunchKernelGGL(k_q_pick, dim3(1), dim3(64), 0, stream, skeys, n, q, out);
+  LT_LAUNCH_CHECK();
+  return LT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// CR_Block (latte/models/hr_module.py:344-420): entropy-weighted KL between matched anchor / hist ST-voxel distributions,
+// mean over the kept rows of every anchor, mean over the anchors.  The reference loops over the anchors in Python with ~12
+// elementwise launches each; here all anchors are rows of one matrix (rows sorted by anchor: anchor_start[B+1]) and the
+// loss is two kernels forward (rows, then a fixed-order per-anchor reduction) and one backward.
+//   w[m]    = exp(-t_e) / (exp(-t_e) + exp(-a_e)),  a_e = ac_pc_ety[ac_p2v[m]], t_e = tr_pc_ety[tr_p2v[m]]   (:373-377)
+//   row[m]  = w[m] * sum_c tr~ * (log tr~ - log ac~),  x~ = (x == 0 ? 1e-8 : x): the clamp acts on PROBABILITIES (Q6, :405-406)
+//   loss    = 1/B * sum_b  sum_{m in b, keep[m]} row[m] / #{m in b : keep[m]}                                 (:407-420)
+// Gradient to ac only (tr is detached, :409): d row / d ac[m,c] = -w[m] * tr~[m,c] / ac[m,c], 0 where ac == 0 (the clamp
+// replaced the element by a constant).
+#define CR_MAXC 64
+__global__ void k_cr_rows(const float* __restrict__ ac, const float* __restrict__ tr, int64_t M, int C,
+                          const float* __restrict__ ac_ety, const int64_t* __restrict__ ac_p2v,
+                          const float* __restrict__ tr_ety, const int64_t* __restrict__ tr_p2v, float* __restrict__ row_w,
+                          float* __restrict__ row_loss) {
+#pragma clang fp contract(off)
+  for (int64_t m = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; m < M; m += (int64_t)gridDim.x * blockDim.x) {
+    float w = 1.f;
+    if (ac_ety) {
+      const float ea = expf(-ac_ety[ac_p2v[m]]), et = expf(-tr_ety[tr_p2v[m]]);
+      w = et / (et + ea);
+    }
+    const float* a = ac + m * C;
+    const float* t = tr + m * C;
+    float kl = 0.f;
+    for (int c = 0; c < C; ++c) {
+      float av = a[c], tv = t[c];
+      if (av == 0.f) av = 1e-8f;
+      if (tv == 0.f) tv = 1e-8f;
+      kl += tv * (logf(tv) - logf(av));   // F.kl_div(log ac, tr, 'none'), summed over the classes in class order
+    }
+    row_w[m] = w;
+    row_loss[m] = w * kl;
+  }
+}
+
+// ONE workgroup: per anchor a fixed-order block reduction of (sum of kept rows, number of kept rows), then the mean over
+// the anchors.  stats[b] = (num_b, den_b) is kept for the backward.  M is a few 1e4..1e5 rows: ~100 rows per thread.
+__global__ __launch_bounds__(1024) void k_cr_reduce(const float* __restrict__ row_loss, const uint8_t* __restrict__ keep,
+                                                    const int* __restrict__ anchor_start, int B, float* __restrict__ stats,
+                                                    float* __restrict__ loss) {
+  __shared__ float s_num[1024], s_den[1024];
+  const int t = threadIdx.x;
+  float total = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const int r0 = anchor_start[b], r1 = anchor_start[b + 1];
+    float num = 0.f, den = 0.f;
+    for (int m = r0 + t; m < r1; m += 1024) {
+      const float k = keep ? (keep[m] ? 1.f : 0.f) : 1.f;
+      num += k * row_loss[m];
+      den += k;
+    }
+    s_num[t] = num;
+    s_den[t] = den;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+      if (t < s) { s_num[t] += s_num[t + s]; s_den[t] += s_den[t + s]; }
+      __syncthreads();
+    }
+    if (t == 0) {
+      stats[2 * b] = s_num[0];
+      stats[2 * b + 1] = s_den[0];
+      total += s_num[0] / s_den[0];        // an anchor without a kept row: 0/0 = NaN, like the reference's mean of nothing
+    }
+    __syncthreads();
+  }
+  if (t == 0) loss[0] = total / (float)B;
+}
+
+__global__ void k_cr_bwd(const float* __restrict__ ac, const float* __restrict__ tr, int64_t M, int C,
+                         const float* __restrict__ row_w, const uint8_t* __restrict__ keep,
+                         const int64_t* __restrict__ row_anchor, const float* __restrict__ stats, int B,
+                         const float* __restrict__ gloss, float* __restrict__ g_ac) {
+  const float g = gloss[0] / (float)B;
+  const int64_t total = M * (int64_t)C;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = e / C;
+    float out = 0.f;
+    if (!keep || keep[m]) {
+      const float av = ac[e];
+      if (av != 0.f) {
+        float tv = tr[e];
+        if (tv == 0.f) tv = 1e-8f;
+        out = -(g * row_w[m] / stats[2 * row_anchor[m] + 1]) * (tv / av);
+      }
+    }
+    g_ac[e] = out;
+  }
+}
+
+static int cr_check(const char* who, int64_t M, int32_t C, int32_t B) {
+  LT_REQUIRE(M >= 0 && M < INT_MAX, LT_ERR_RANGE, "%s: M out of range", who);
+  LT_REQUIRE(C >= 1 && C <= CR_MAXC, LT_ERR_ARG, "%s: C=%d must be in [1,%d]", who, C, CR_MAXC);
+  LT_REQUIRE(B >= 1, LT_ERR_ARG, "%s: B=%d anchors", who, B);
+  return LT_OK;
+}
+
+extern "C" int lt_cr_loss_fwd(const float* ac, const float* tr, int64_t M, int32_t C, const float* ac_pc_ety,
+                              const int64_t* ac_p2v, const float* tr_pc_ety, const int64_t* tr_p2v, const uint8_t* keep,
+                              const int32_t* anchor_start, int32_t B, float* row_w, float* row_loss, float* anchor_stats,
+                              float* loss, hipStream_t stream) {
+  int rc = cr_check("lt_cr_loss_fwd", M, C, B);
+  if (rc) return rc;
+  LT_REQUIRE(anchor_start && anchor_stats && loss && (M == 0 || (ac && tr && row_w && row_loss)), LT_ERR_ARG,
+             "lt_cr_loss_fwd: null pointer");
+  const bool ety = ac_pc_ety || ac_p2v || tr_pc_ety || tr_p2v;
+  LT_REQUIRE(!ety || (ac_pc_ety && ac_p2v && tr_pc_ety && tr_p2v), LT_ERR_ARG,
+             "lt_cr_loss_fwd: the four entropy-weight arguments come together (all NULL: weight 1)");
+  if (M > 0) {
+    hipLaunchKernelGGL(k_cr_rows, dim3(lt_grid(M, 256)), dim3(256), 0, stream, ac, tr, M, C, ac_pc_ety, ac_p2v, tr_pc_ety,
+                       tr_p2v, row_w, row_loss);
+    LT_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(k_cr_reduce, dim3(1), dim3(1024), 0, stream, row_loss, keep, anchor_start, B, anchor_stats, loss);
+  LT_LAUNCH_CHECK();
+  return LT_OK;
+}
+
+extern "C" int lt_cr_loss_bwd(const float* ac, const float* tr, int64_t M, int32_t C, const float* row_w, const uint8_t* keep,
+                              const int64_t* row_anchor, const float* anchor_stats, int32_t B, const float* gloss,
+                              float* g_ac, hipStream_t stream) {
+  int rc = cr_check("lt_cr_loss_bwd", M, C, B);
+  if (rc) return rc;
+  if (M == 0) return LT_OK;
+  LT_REQUIRE(ac && tr && row_w && row_anchor && anchor_stats && gloss && g_ac, LT_ERR_ARG, "lt_cr_loss_bwd: null pointer");
+  hipLaunchKernelGGL(k_cr_bwd, dim3(lt_grid(M * (int64_t)C, 256)), dim3(256), 0, stream, ac, tr, M, C, row_w, keep, row_anchor,
+                     anchor_stats, B, gloss, g_ac);
   LT_LAUNCH_CHECK();
   return LT_OK;
 }

@@ -274,11 +274,27 @@ def _allreduce_small(t: torch.Tensor, group) -> torch.Tensor:
     return t
 
 
+_ROWS_SCALARS: dict = {}
+
+
+def _rows_scalar(rows: int, device) -> torch.Tensor:
+    """fp64 [1] device tensor holding a row count, cached per (count, device): the same ~10 counts recur in every layer
+    of every step, and a fresh torch.tensor(..., device=) is a host-to-device copy per BatchNorm"""
+    key = (int(rows), str(device))
+    t = _ROWS_SCALARS.get(key)
+    if t is None:
+        if len(_ROWS_SCALARS) > 256:
+            _ROWS_SCALARS.clear()
+        t = _ROWS_SCALARS[key] = torch.tensor([float(rows)], dtype=torch.float64, device=device)
+    return t
+
+
 def sync_batch_stats(mean: torch.Tensor, var: torch.Tensor, rows: int, group):
     """local (mean, biased var, rows) of every rank -> global (mean, var, total rows); combined in fp64 from
-    [sum x, sum x^2, rows]"""
+    [sum x, sum x^2, rows].  A rank with rows == 0 contributes zeros: every rank issues the same collective whatever its
+    local row count is (a shard with an empty coarse level must not leave its peers waiting)."""
     m, v = mean.double(), var.double()
-    vec = torch.cat([m * rows, (v + m * m) * rows, torch.tensor([float(rows)], dtype=torch.float64, device=mean.device)])
+    vec = torch.cat([m * rows, (v + m * m) * rows, _rows_scalar(rows, mean.device)])
     vec = _allreduce_small(vec, group)
     C = mean.numel()
     n = vec[2 * C]
@@ -293,13 +309,19 @@ class _BatchNorm(Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, residual, eps, relu, stats_out, post_add=False):
-        mean, var = ops.bn_stats(x)
+        if x.shape[0] > 0:
+            mean, var = ops.bn_stats(x)
+        else:   # cross-rank statistics only (batch_norm refuses otherwise): this rank has no row at this level
+            mean, var = x.new_zeros(x.shape[1]), x.new_zeros(x.shape[1])
         ctx.sync = None
         if SYNC_BN_GROUP is not None:
             mean, var, n_total = sync_batch_stats(mean, var, x.shape[0], SYNC_BN_GROUP)
             ctx.sync = (SYNC_BN_GROUP, n_total, x.shape[0])
         post_add = bool(post_add and relu and residual is not None)
-        y = ops.bn_apply(x, mean, var, gamma, beta, eps, residual=residual, relu=relu, post_add=post_add)
+        if x.shape[0] > 0:
+            y = ops.bn_apply(x, mean, var, gamma, beta, eps, residual=residual, relu=relu, post_add=post_add)
+        else:
+            y = torch.empty_like(x)
         ctx.eps, ctx.relu, ctx.post_add = eps, relu, post_add
         ctx.has_res = residual is not None
         # ReLU mask in the backward: from y when a residual was added before the ReLU, otherwise rebuilt from x (y is not
@@ -318,6 +340,13 @@ class _BatchNorm(Function):
         sync = None
         if ctx.sync is not None:
             group, n_total, rows = ctx.sync
+            if rows == 0:   # no local row: still take part in the backward's collective, with zero sums
+                z = torch.zeros(2 * x.shape[1], dtype=torch.float32, device=x.device)
+                both = _allreduce_small(z, group)
+                C = x.shape[1]
+                e = torch.empty_like(x)
+                return (e if need_dx else None), both[C:].contiguous(), both[:C].contiguous(), (e if need_dres else None), \
+                    None, None, None, None
 
             def sync(sum_g, sum_gx):
                 both = _allreduce_small(torch.cat([sum_g, sum_gx]), group)
@@ -384,8 +413,9 @@ def conv_bn(feats, weight, gamma, beta, kmap: KernelMap, transposed=False, resid
 
 
 def batch_norm(x, gamma, beta, eps=1e-5, residual=None, relu=False, stats_out=None, post_add=False):
-    if x.shape[0] * 1 == 1:
-        # same refusal as torch.nn.functional.batch_norm in training mode
+    if x.shape[0] <= 1 and SYNC_BN_GROUP is None:
+        # same refusal as torch.nn.functional.batch_norm in training mode; with cross-rank statistics the LOCAL row count
+        # says nothing (and every rank must reach the collective), so the call goes through
         raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(x.shape)}")
     return _BatchNorm.apply(x, gamma, beta, residual, float(eps), bool(relu), stats_out, bool(post_add))
 

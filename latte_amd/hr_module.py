@@ -80,8 +80,29 @@ def _decode_xyz(keys: torch.Tensor, cb: int) -> torch.Tensor:
 
 
 class _HRResult(dict):
-    """HR_Block's output dict (the reference's 11 keys) plus, as an attribute, the anchor index of every matched row"""
-    row_anchor = None
+    """HR_Block's output dict (the reference's 11 keys) plus, as attributes, what CR_Block needs to treat all anchors as
+    rows of ONE matrix: the anchor index of every matched row, the row offsets of the anchors (device), and the unsplit
+    tensors the per-anchor lists are views of"""
+    row_anchor = None      # int64 [M] device
+    anchor_start = None    # int32 [B+1] device
+    flat = None            # dict(ac_logits, tr_logits, ac_p2v_indices, tr_p2v_indices): the tensors before the split
+
+
+class _CRLoss(Function):
+    """CR_Block's loss over all anchors at once (lt_cr_loss_fwd / lt_cr_loss_bwd); gradient to the anchor probabilities."""
+
+    @staticmethod
+    def forward(ctx, ac, tr, anchor_start, row_anchor, B, keep, ac_pc_ety, ac_p2v, tr_pc_ety, tr_p2v):
+        loss, row_w, stats, keep8 = ops.cr_loss_fwd(ac, tr, anchor_start, B, keep, ac_pc_ety, ac_p2v, tr_pc_ety, tr_p2v)
+        ctx.save_for_backward(ac, tr, row_w, stats, row_anchor, keep8)
+        ctx.B = B
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        ac, tr, row_w, stats, row_anchor, keep8 = ctx.saved_tensors
+        g_ac = ops.cr_loss_bwd(ac, tr, row_w, keep8, row_anchor, stats, ctx.B, g.float().contiguous())
+        return g_ac, None, None, None, None, None, None, None, None, None
 
 
 class HR_Block(nn.Module):
@@ -193,6 +214,7 @@ class HR_Block(nn.Module):
                     a_inv=a_inv, a_seg=a_seg, a_sel_l=a_sel_l, t_sel_l=t_sel_l, per_anchor=per_anchor,
                     vox=_decode_xyz(matched_keys, cb), ac_p2v=ac_first[a_sel_l], tr_p2v=tr_first[t_sel_l],
                     row_anchor=(matched_keys >> (3 * cb)),
+                    anchor_start=d(np.concatenate([[0], np.cumsum(per_anchor)]), torch.int32),
                     h_start_d=d(h_start, torch.int64), frame_seg_d=d(frame_seg, torch.int32), seg_out_d=seg_out_d)
 
     def forward(self, anchor_batch: Dict, anchor_type: str, hist_batch: Dict, hist_type: str, geo: Dict = None) -> Dict:
@@ -220,8 +242,9 @@ class HR_Block(nn.Module):
         vox = geo["vox"]
         split = lambda t: list(torch.split(t, per_anchor, 0))
         tr_logits_all = tr_voxel_probs[t_sel_l]
+        ac_logits_all = gather_rows(ac_voxel_probs, a_sel_l)
         out = _HRResult({
-            "ac_logits": split(gather_rows(ac_voxel_probs, a_sel_l)),
+            "ac_logits": split(ac_logits_all),
             "ac_voxels": split(vox),
             "tr_logits": split(tr_logits_all),
             "tr_voxels": split(vox.clone()),
@@ -233,6 +256,9 @@ class HR_Block(nn.Module):
             "hs_pc_ety": hs_pc_ety,
         })
         out.row_anchor = geo["row_anchor"]   # anchor of every matched row (device), for CR_Block's per-anchor means
+        out.anchor_start = geo["anchor_start"]
+        out.flat = {"ac_logits": ac_logits_all, "tr_logits": tr_logits_all, "ac_p2v_indices": geo["ac_p2v"],
+                    "tr_p2v_indices": geo["tr_p2v"]}
         if self.conf_perc is not None and self.conf_perc > 0.0:
             out["tr_conf_mask"] = refine_ety(tr_voxel_ety, tr_logits_all.argmax(1), self.conf_perc, num_classes=C)
         else:
@@ -249,28 +275,47 @@ class CR_Block(nn.Module):
         self.conf_mask = conf_mask
         self.ety_weight = ety_weight
 
+    @staticmethod
+    def _flat(logit_dict, key: str, sizes):
+        """all anchors' rows of logit_dict[key] as ONE tensor: the tensor HR_Block split the list from when the list still is
+        that split (same storage, same offsets -- the reference's callers pass HR_Block's dict on unchanged,
+        latte/tta/tools/latte.py:276-291), a concatenation otherwise"""
+        lst = logit_dict[key]
+        flat = getattr(logit_dict, "flat", None)
+        t = flat.get(key) if flat else None
+        if t is not None and t.shape[0] == sum(sizes) and len(lst) == len(sizes):
+            row_bytes = t.stride(0) * t.element_size() if t.dim() > 0 else 0
+            off, ok = 0, True
+            for part, n in zip(lst, sizes):
+                if part.shape[0] != n or (n and part.data_ptr() != t.data_ptr() + off * row_bytes):
+                    ok = False
+                    break
+                off += n
+            if ok:
+                return t
+        return torch.cat(list(lst), 0)
+
     def forward(self, logit_dict: Dict[str, torch.Tensor], self_corr: bool = False) -> torch.Tensor:
-        ac_list, tr_list = logit_dict["ac_logits"], logit_dict["tr_logits"]
+        """-> mean over the anchors of the masked mean of  w * KL(tr || ac)  over the anchor's matched voxels.  Two HIP
+        launches forward, one backward (lt_cr_loss_fwd / _bwd) for ALL anchors; matched anchor / hist voxel lists are identical
+        and sorted, so the reference's two argsorts (:359-360) are the identity (Q3)."""
+        ac_list = logit_dict["ac_logits"]
         sizes = [int(t.shape[0]) for t in ac_list]
-        ac = torch.cat(list(ac_list), 0)
-        tr = torch.cat(list(tr_list), 0).detach()
-        M = ac.shape[0]
+        B, M = len(sizes), sum(sizes)
+        ac = self._flat(logit_dict, "ac_logits", sizes)
+        tr = self._flat(logit_dict, "tr_logits", sizes).detach()
         dev = ac.device
-        # matched anchor/hist voxel lists are identical and sorted => the reference's two argsorts are the identity (Q3)
+        anchor_start = getattr(logit_dict, "anchor_start", None)
+        row_anchor = getattr(logit_dict, "row_anchor", None)
+        if anchor_start is None or row_anchor is None or row_anchor.numel() != M or anchor_start.numel() != B + 1:
+            anchor_start = torch.as_tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int32).to(dev)
+            row_anchor = torch.repeat_interleave(torch.arange(B, device=dev), torch.as_tensor(sizes, device=dev), output_size=M)
+        ety = {}
         if self.ety_weight and not self_corr:
-            a_e = logit_dict["ac_pc_ety"][torch.cat(list(logit_dict["ac_p2v_indices"]), 0)]
-            t_e = logit_dict["tr_pc_ety"][torch.cat(list(logit_dict["tr_p2v_indices"]), 0)]
-            weight = torch.exp(-t_e) / (torch.exp(-t_e) + torch.exp(-a_e))
-        else:
-            weight = torch.ones(M, device=dev)
-        tr = torch.where(tr == 0.0, torch.full_like(tr, 1e-8), tr)  # Q6: applied to probabilities
-        ac = torch.where(ac == 0.0, torch.full_like(ac, 1e-8), ac)
-        row = weight * F.kl_div(torch.log(ac), tr, reduction="none").sum(1)
-        keep = logit_dict["tr_conf_mask"][:M].to(row.dtype) if self.conf_mask else torch.ones(M, device=dev)
-        anchor_of_row = getattr(logit_dict, "row_anchor", None)
-        if anchor_of_row is None or anchor_of_row.numel() != M:
-            anchor_of_row = torch.repeat_interleave(torch.arange(len(sizes), device=dev),
-                                                    torch.as_tensor(sizes, device=dev), output_size=M)
-        num = torch.zeros(len(sizes), dtype=row.dtype, device=dev).index_add(0, anchor_of_row, row * keep)
-        den = torch.zeros(len(sizes), dtype=row.dtype, device=dev).index_add(0, anchor_of_row, keep)
-        return (num / den).sum() / len(sizes)
+            ety = dict(ac_pc_ety=logit_dict["ac_pc_ety"].detach().float().contiguous(),
+                       ac_p2v=self._flat(logit_dict, "ac_p2v_indices", sizes).long(),
+                       tr_pc_ety=logit_dict["tr_pc_ety"].detach().float().contiguous(),
+                       tr_p2v=self._flat(logit_dict, "tr_p2v_indices", sizes).long())
+        keep = logit_dict["tr_conf_mask"][:M].contiguous() if self.conf_mask else None
+        return _CRLoss.apply(ac.float().contiguous(), tr.float().contiguous(), anchor_start, row_anchor, B, keep,
+                             ety.get("ac_pc_ety"), ety.get("ac_p2v"), ety.get("tr_pc_ety"), ety.get("tr_p2v"))

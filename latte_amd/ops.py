@@ -620,6 +620,40 @@ def pseudo_label_fuse(logits_2d, logits_3d, fov_idx, st_ety_2d, st_ety_3d, thr_2
     return pc2, pc3, conf, label
 
 
+def cr_loss_fwd(ac, tr, anchor_start, B: int, keep=None, ac_pc_ety=None, ac_p2v=None, tr_pc_ety=None, tr_p2v=None):
+    """-> (loss [1], row_w [M], anchor_stats [B,2]); see lt_cr_loss_fwd.  keep: uint8 / bool [M] or None."""
+    ac = _chk(ac, torch.float32, "cr ac")
+    tr = _chk(tr, torch.float32, "cr tr")
+    M, C = ac.shape
+    assert tr.shape == ac.shape and anchor_start.numel() == B + 1
+    dev = ac.device
+    row_w = torch.empty(M, dtype=torch.float32, device=dev)
+    row_loss = torch.empty(M, dtype=torch.float32, device=dev)
+    stats = torch.empty((B, 2), dtype=torch.float32, device=dev)
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    if keep is not None:
+        keep = _chk(keep.view(torch.uint8) if keep.dtype == torch.bool else keep, torch.uint8, "cr keep")
+        assert keep.numel() >= M
+    ety = ac_pc_ety is not None
+    _lib.call("lt_cr_loss_fwd", _p(ac), _p(tr), M, int(C),
+              _p(_chk(ac_pc_ety, torch.float32, "cr ac_pc_ety")) if ety else None,
+              _p(_chk(ac_p2v, torch.int64, "cr ac_p2v")) if ety else None,
+              _p(_chk(tr_pc_ety, torch.float32, "cr tr_pc_ety")) if ety else None,
+              _p(_chk(tr_p2v, torch.int64, "cr tr_p2v")) if ety else None,
+              _p(keep), _p(_chk(anchor_start, torch.int32, "cr anchor_start")), int(B), _p(row_w), _p(row_loss), _p(stats),
+              _p(loss), _stream())
+    return loss, row_w, stats, keep
+
+
+def cr_loss_bwd(ac, tr, row_w, keep, row_anchor, stats, B: int, gloss):
+    M, C = ac.shape
+    g_ac = torch.empty_like(ac)
+    _lib.call("lt_cr_loss_bwd", _p(ac), _p(tr), M, int(C), _p(row_w), _p(keep),
+              _p(_chk(row_anchor, torch.int64, "cr row_anchor")), _p(stats), int(B),
+              _p(_chk(gloss.reshape(1), torch.float32, "cr gloss")), _p(g_ac), _stream())
+    return g_ac
+
+
 # ------------------------------------------------------------------ conv -> BN [+ residual] [+ ReLU] composites
 def conv_bn_fwd(feats, packed, plan, K: int, Vout: int, cout: int, gamma, beta, eps: float, residual, relu: bool):
     """-> (conv_out, y, mean, var).  One host call (lt_conv_bn_fwd): conv with statistics epilogue, finalize, BN apply."""

@@ -23,7 +23,7 @@ from .functional import gather_rows
 from .hr_module import CR_Block, HR_Block
 from .spvcnn import inverse_to_all
 
-__all__ = ["configure_model_norm", "configure_model_all", "create_ema_model", "update_ema_norm", "update_ema_all", "refine_pseudo_labels", "pc2img_logit",
+__all__ = ["ensure_side_stream", "MAX_STEPS_IN_FLIGHT", "configure_model_norm", "configure_model_all", "create_ema_model", "update_ema_norm", "update_ema_all", "refine_pseudo_labels", "pc2img_logit",
            "LatteStep", "FlatAdamEMA", "shard_scan_offset", "shard_sequences", "allreduce_mean_grads"]
 
 
@@ -187,6 +187,10 @@ class FlatAdamEMA:
         # head is outside the Latte losses).  torch.optim.Adam skips such a parameter instead; the result is the same
         # while weight_decay == 0 and the parameter never gets a gradient later (its moments stay zero).
         self.allow_missing = bool(allow_missing_grads)
+        if self.allow_missing and weight_decay != 0.0:
+            # torch.optim.Adam SKIPS a parameter without a gradient; a zero gradient is the same only without weight decay
+            raise ValueError("FlatAdamEMA: allow_missing_grads counts a missing gradient as zero, which differs from "
+                             "torch.optim.Adam (it skips the parameter) once weight_decay != 0")
         self.params = list(params)
         if not self.params:
             raise ValueError("FlatAdamEMA: no parameters")
@@ -206,6 +210,22 @@ class FlatAdamEMA:
         self.exp_avg = torch.zeros_like(self.flat_p)
         self.exp_avg_sq = torch.zeros_like(self.flat_p)
         self.steps = 0
+        self._ema_params = ema_params
+
+    def _check_aliasing(self) -> None:
+        """The parameters must still be views of the flat buffers the kernel updates.  Module._apply (model.cuda() /
+        .float() / .to()) or another `.data` assignment re-points them silently -- the kernel would go on updating
+        buffers the model no longer sees.  First and last parameter of both lists: O(1) per step."""
+        for flat, plist, who in ((self.flat_p, self.params, "student"), (self.flat_e, self._ema_params, "teacher")):
+            if flat is None:
+                continue
+            last = plist[-1]
+            ok = (plist[0].data_ptr() == flat.data_ptr()
+                  and last.data_ptr() == flat.data_ptr() + 4 * (flat.numel() - last.numel()))
+            if not ok:
+                raise RuntimeError(f"FlatAdamEMA: the {who} parameters no longer alias the optimizer's flat buffer (the model "
+                                   "was moved / cast / had .data reassigned after the optimizer was built); rebuild the "
+                                   "optimizer (LatteStep) after such a change")
 
     @staticmethod
     def _flatten(params):
@@ -256,6 +276,7 @@ class FlatAdamEMA:
             setattr(self, k, tuple(v) if k == "betas" else v)
 
     def step(self, grad_scale: float = 1.0) -> None:
+        self._check_aliasing()
         self.steps += 1
         ops.adam_ema_step(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.flat_e, self.lr, self.betas[0],
                           self.betas[1], self.eps, self.weight_decay, self.steps, self.ema_alpha, grad_scale)
@@ -304,12 +325,35 @@ _KEEP_CACHE = bool(__import__("os").environ.get("LATTE_DIAG_KEEP_INDEX_CACHE"))
 
 _SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
 
+# Stream discipline of a rank (DESIGN 6b "Streams: the invariants").  A process owns few hardware queues (GPU_MAX_HW_QUEUES =
+# 4 on the box) and HIP deals streams onto them round-robin, so the product creates exactly ONE stream of its own per device
+# per process -- the side stream below -- and otherwise lives on the caller's current stream; with the nccl backend torch's
+# process group adds one collective stream: main + side + collective = 3 <= 4 queues.  MAX_STEPS_IN_FLIGHT bounds how far
+# the host may run ahead of the GPU (step i is not issued before step i - MAX_STEPS_IN_FLIGHT has finished on the GPU).
+MAX_STEPS_IN_FLIGHT = 2
+
+
+def ensure_side_stream(device=None) -> "torch.cuda.Stream":
+    """The side stream of `device` (default: the current device), created on first use -- ONE per device per process,
+    high priority.  Call it right after torch.cuda.set_device() and BEFORE torch.distributed.init_process_group in a
+    multi-rank process, so that the order in which the process creates its streams (and with it the stream -> hardware
+    queue assignment) is the same on every rank and in every run: main (the null stream, exists), side, collective."""
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    if dev is None:
+        dev = torch.cuda.current_device()
+    s = _SIDE_STREAMS.get(dev)
+    if s is None:
+        prio = int(__import__("os").environ.get("LATTE_DIAG_SIDE_PRIORITY", "-1"))  # small dependent kernels: ahead of the big ones
+        with torch.cuda.device(dev):
+            s = _SIDE_STREAMS[dev] = torch.cuda.Stream(priority=prio)
+    return s
+
 
 class LatteStep:
     def __init__(self, model_3d: nn.Module, num_classes: int, hr_cfg: Dict, lr: float = 1e-3, conf_perc=None,
                  lambda_hr_23: float = 0.3, lambda_hr_32: float = 0.3, lambda_ety_ps: float = 1.0, class_weights=None,
                  process_group=None, side_stream: bool = True, fused_optimizer: bool = True, sync_bn: bool = False,
-                 update_params: str = "norm"):
+                 update_params: str = "norm", force_collective: bool = False):
         # update_params: cfg.TRAIN.UPDATE_PARAMS (latte/tta/tta.py:129-138) -- "norm" (every shipped latte.yaml: only the
         # norm layers' gamma / beta train) or "all" (every parameter trains: conv kernels through lt_spconv_bwd_weight)
         self.update_params = str(update_params).lower()
@@ -343,6 +387,9 @@ class LatteStep:
         self.num_classes = num_classes
         self.pg = process_group
         self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
+        # rehearsals: issue the gradient all-reduce even in a one-rank group (the stream / thread topology of an N-rank
+        # run -- main, side, the process group's collective stream and watchdog thread -- on a one-GPU box)
+        self.force_collective = bool(force_collective) and process_group is not None
         # sync_bn (N > 1 only): the exact-parity mode of SURVEY 8e -- BatchNorm statistics and their backward sums are
         # all-reduced per layer, so the sharded step computes what ONE GPU would on the whole batch; the BatchNorm
         # parameter gradients are then global sums on every rank and are not all-reduced again
@@ -358,6 +405,9 @@ class LatteStep:
         self.hr_side_stream = side_stream
         self._side = None
         self._pre = None   # (batch, tables, geo23, geo32) built ahead by prefetch()
+        self._inflight: List = []   # end-of-step events of the iterations the GPU may still be working on
+        if self.hr_side_stream and self.params[0].is_cuda:
+            ensure_side_stream(self.params[0].device)   # created now, not inside the first step (deterministic creation order)
 
     # -------------------------------------------------------------------------------------------------
     def _tick(self, name: str):
@@ -409,11 +459,12 @@ class LatteStep:
             # the box) and HIP deals streams onto them round-robin, so a fresh stream per LatteStep instance eventually
             # lands on the main stream's queue and the "side" work queues up behind the convs (measured: the 4th
             # instance of a process ran 45 ms per step instead of 29)
-            dev = torch.cuda.current_device()
-            if dev not in _SIDE_STREAMS:
-                prio = int(__import__("os").environ.get("LATTE_DIAG_SIDE_PRIORITY", "-1"))  # small dependent kernels: ahead of the big ones
-                _SIDE_STREAMS[dev] = torch.cuda.Stream(priority=prio)
-            self._side = _SIDE_STREAMS[dev]
+            self._side = ensure_side_stream(self.params[0].device)
+        # the invariant the stream plan rests on: this instance never holds a stream the process registry does not know
+        assert self._side is _SIDE_STREAMS.get(self._side.device.index), "LatteStep: side stream outside the per-device registry"
+        if torch.cuda.current_stream() == self._side:
+            raise RuntimeError("LatteStep: called with the side stream as the current stream -- main and side must be two "
+                               "streams (the side stream waits for events of the main one and vice versa)")
         return self._side
 
     def _hr_inputs(self, batch: Dict, tab: Dict):
@@ -452,25 +503,35 @@ class LatteStep:
         the join."""
         side = self._side_stream()
         if side is None:
+            if callable(batch):
+                raise RuntimeError("LatteStep.prefetch: a batch factory needs the side stream")
             return
         import threading
         from .tensor import SparseTensor
-        dev = batch["lidar"].C.device
+        # `batch` may be a FACTORY: a callable that produces the batch dict (raw points -> H2D -> quantize -> collate,
+        # latte_amd.workload.batch_from_raw).  It then runs in the helper thread ON THE SIDE STREAM, one iteration ahead --
+        # where a loader would put the input voxelization -- and step(None) picks its batch up.
+        factory = batch if callable(batch) else None
+        dev = self.params[0].device if factory is not None else batch["lidar"].C.device
         box: Dict = {}
-        ready = self._ready_event(batch)     # on the calling thread: its current stream is the producer's
+        ready = None if factory is not None else self._ready_event(batch)   # on the calling thread: its current stream is the producer's
 
         def body():
             try:
                 with torch.cuda.device(dev), torch.no_grad(), torch.cuda.stream(side):
-                    side.wait_event(ready)
-                    tab = self._batch_tables(batch)
-                    x = batch["lidar"]
+                    if factory is not None:
+                        b = factory()            # H2D + input voxelization + collate, on the side stream
+                    else:
+                        b = batch
+                        side.wait_event(ready)
+                    tab = self._batch_tables(b)
+                    x = b["lidar"]
                     view = SparseTensor(x.F, x.C, x.s)   # same tensors, own cache slot
                     self.model.net_3d.prepare(view)
-                    a2, h2, a3, h3 = self._hr_inputs(batch, tab)
+                    a2, h2, a3, h3 = self._hr_inputs(b, tab)
                     box["geo23"] = self.hr.geometry(a2, "2D", h3, "3D")
                     box["geo32"] = self.hr.geometry(a3, "3D", h2, "2D")
-                    box["tab"], box["cache"] = tab, view._lt_cache
+                    box["batch"], box["tab"], box["cache"] = b, tab, view._lt_cache
                     # what the consumer waits for: this batch's structures, not whatever the side stream does next
                     box["done"] = torch.cuda.Event()
                     box["done"].record(side)
@@ -481,9 +542,9 @@ class LatteStep:
         th.start()
         self._pre = (batch, th, box)
 
-    def _take_prefetched(self, batch: Dict):
-        """-> (tables, geo23, geo32) built ahead for `batch` by prefetch() (joins the helper thread, installs the index
-        structures on the batch), or None"""
+    def _take_prefetched(self, batch):
+        """-> (tables, geo23, geo32, done event, batch) built ahead for `batch` by prefetch() (joins the helper thread,
+        installs the index structures on the batch), or None.  batch None: whatever batch the prefetched factory made."""
         pre, self._pre = self._pre, None
         if pre is None:
             return None
@@ -491,10 +552,15 @@ class LatteStep:
         th.join()
         if "error" in box:
             raise box["error"]
-        if b is not batch or self._side_stream() is None:
+        if self._side_stream() is None:
+            return None
+        if batch is None and callable(b):
+            batch = box["batch"]
+            _record_stream_tree(batch, torch.cuda.current_stream())   # its tensors were allocated on the side stream
+        elif b is not batch:
             return None
         batch["lidar"]._lt_cache = box["cache"]
-        return box["tab"], box["geo23"], box["geo32"], box["done"]
+        return box["tab"], box["geo23"], box["geo32"], box["done"], batch
 
     def forward_backward(self, batch: Dict, pre=None):
         """-> dict of losses.  batch: see latte_amd.workload.build_batch.
@@ -515,7 +581,7 @@ class LatteStep:
         if pre is not None:
             # built one iteration ahead by prefetch(); wait for THAT work only (the helper of the next batch may already be
             # queueing on the side stream)
-            tab, geo23, geo32, done = pre
+            tab, geo23, geo32, done = pre[:4]
             main.wait_event(done)
             _record_stream_tree(batch["lidar"]._lt_cache, main)
             _record_stream_tree(tab, main)
@@ -604,7 +670,7 @@ class LatteStep:
                 update_ema_all(self.ema_model, self.model, 0.99, params=self._ema_pairs)
             return
         flat = self.optimizer.gather_grads()
-        if self.world > 1 and not self.sync_bn:
+        if (self.world > 1 or self.force_collective) and not self.sync_bn:
             # the only collective of the path: ONE all-reduce (RCCL over xGMI) of the flat gradient buffer; the mean is
             # folded into the update kernel (grad_scale)
             if flat.is_cuda and torch.distributed.get_backend(self.pg) == "gloo":
@@ -628,13 +694,24 @@ class LatteStep:
         finally:
             LF.SYNC_BN_GROUP = prev
 
-    def step(self, batch: Dict, next_batch: Dict | None = None):
+    def step(self, batch: Dict | None, next_batch=None):
         """One TTA iteration on `batch`.  next_batch (optional): the batch of the NEXT iteration -- a helper thread starts
-        building its input-only structures on the side stream right away (prefetch), beside this iteration."""
+        building its input-only structures on the side stream right away (prefetch), beside this iteration -- or a
+        callable that makes it (see prefetch); the next call is then step(None, ...): "the batch announced last time"."""
         self._tick("step_begin")
+        # bound the host's run-ahead: iteration i is not issued before iteration i - MAX_STEPS_IN_FLIGHT has finished on
+        # the GPU (a host wait on an event recorded at the end of that step; free while the step is GPU-bound, the host
+        # is < 1 step ahead then).  It keeps the number of outstanding packets / completion signals / allocator blocks of
+        # every stream bounded by two iterations' worth, whatever the caller's loop does.
+        while len(self._inflight) >= MAX_STEPS_IN_FLIGHT:
+            self._inflight.pop(0).synchronize()
         # one TTA iteration = one new batch: index structures are built once per iteration (ahead of it by prefetch(), or
         # by the teacher forward) and shared with the student forward, never carried over from an earlier iteration
         pre = self._take_prefetched(batch)
+        if batch is None:
+            if pre is None:
+                raise ValueError("LatteStep.step(None): no batch factory was announced by the previous step / prefetch()")
+            batch = pre[4]
         if pre is None and not _KEEP_CACHE:
             batch["lidar"]._lt_cache = None
         if next_batch is not None:
@@ -643,6 +720,10 @@ class LatteStep:
         losses = self._with_sync_bn(self.forward_backward, batch, pre)
         self._update()
         self._tick("optim_ema")
+        if self.params[0].is_cuda:
+            ev = torch.cuda.Event()
+            ev.record()          # on the main (current) stream: the end of this iteration
+            self._inflight.append(ev)
         return losses
 
     def close(self) -> None:

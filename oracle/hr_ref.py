@@ -157,9 +157,11 @@ def hr_forward(anchor_batch, anchor_type, hist_batch, hist_type, temp_wd_size, m
     return out
 
 
-def cr_forward(d, conf_mask=True, ety_weight=True):
-    """CR_Block.forward restated; matched anchor/hist voxel lists are identical and sorted, so both argsorts of the
-    reference (:359-360) are the identity (Q3)."""
+def cr_forward(d, conf_mask=True, ety_weight=True, self_corr=False):
+    """CR_Block.forward restated (hr_module.py:344-420); matched anchor/hist voxel lists are identical and sorted, so both
+    argsorts of the reference (:359-360) are the identity (Q3).  self_corr: the reference's flag that switches the entropy
+    weights off (:347,373,379)."""
+    ety_weight = ety_weight and not self_corr
     losses, left = [], 0
     for i, (ac, tr) in enumerate(zip(d["ac_logits"], d["tr_logits"])):
         right = left + ac.shape[0]

@@ -748,3 +748,47 @@ def test_conv_epilogue_statistics_with_a_large_mean(scans_small):
     assert 500 < ratio2 < 2000
     assert torch.allclose(mean, m2, rtol=1e-6)
     assert float(((var - v2).abs() / v2).max()) < 1e-7 * (1 + ratio2) * 8
+
+
+def test_bf16x3_pack_and_launch_sides_use_one_rule(scans_small):
+    """Under lt_conv_set_precision(1) the pack side (functional._packed -> bf16 hi|lo image) and the launch side decide with
+    ONE predicate (lt_conv_uses_bf16).   Cout = 80 / 112 (5 / 7 column tiles: no bf16 shape) stay fp32 on both
+    sides and give the fp32 result bit for bit; a conv the rule claims but the kernel cannot address (operands past 2 GiB),
+    or an explicit fp32 variant over a bf16 image, is an error -- never an fp32 kernel reading a bf16 image."""
+    from latte_amd import _lib, ops
+    from latte_amd import sparse_modules as spnn
+    from latte_amd.tensor import SparseTensor
+    c = scans_small["coords"]
+    g = torch.Generator().manual_seed(3)
+    V = c.shape[0]
+    try:
+        for cin, cout in ((64, 80), (96, 112), (64, 96)):
+            conv = spnn.Conv3d(cin, cout, 3).cuda()
+            conv.kernel.requires_grad_(False)
+            f = torch.randn(V, cin, generator=g).cuda()
+            ops.set_conv_precision("f32")
+            want = conv(SparseTensor(f, dev(c), 1)).F
+            ops.set_conv_precision("bf16x3")
+            got = conv(SparseTensor(f, dev(c), 1)).F
+            if cout in (80, 112):
+                assert not ops.conv_uses_bf16(cin, cout)
+                assert torch.equal(got, want), (cin, cout)             # every output column written, by the fp32 kernel
+            else:
+                assert ops.conv_uses_bf16(cin, cout)
+                assert 0 < rel_err(got, want) < 2e-5
+        # a claimed conv whose operands the 32-bit buffer offsets cannot reach: refused (LT_ERR_RANGE), output untouched
+        ops.set_conv_precision("bf16x3")
+        x = SparseTensor(torch.zeros(V, 4, device="cuda"), dev(c), 1)
+        kmap, _ = spnn.build_kernel_map(x, 3, 1, 1)
+        big = torch.empty((2_200_000, 256), dtype=torch.float32, device="cuda")    # 2.25 GB of rows; never read
+        pw = ops.pack_weights(torch.zeros(27, 256, 64, device="cuda"), 4)
+        with pytest.raises(_lib.LatteHipError, match="2 GiB"):
+            ops.spconv_plan(big, pw, kmap.plan(), 27, V, 64)
+        del big
+        # an explicit fp32 variant while the weights of this width are bf16 images: refused as well
+        f = torch.randn(V, 64, generator=g).cuda()
+        pw = ops.pack_weights(torch.zeros(27, 64, 64, device="cuda"), 4)
+        with pytest.raises(_lib.LatteHipError, match="fp32 kernel"):
+            ops.spconv_plan(f, pw, kmap.plan(), 27, V, 64, variant=2142)
+    finally:
+        ops.set_conv_precision("f32")

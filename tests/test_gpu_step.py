@@ -342,3 +342,23 @@ def test_rotating_batches_with_prefetch_stay_finite():
         assert all(np.isfinite(float(v)) for v in losses.values())
     for (n, p), (_, e) in zip(step.model.named_parameters(), step.ema_model.named_parameters()):
         assert torch.isfinite(p).all() and torch.isfinite(e).all(), n
+
+
+def test_flat_optimizer_notices_when_the_model_stops_aliasing_its_buffers():
+    """ FlatAdamEMA re-points the parameters at slices of its flat buffers; a later Module._apply (.float(),
+    .to(), .cuda()) or `.data` assignment breaks that silently.  step() checks it and raises; allow_missing_grads with
+    weight decay (not equivalent to torch.optim.Adam's skipping) is refused up front."""
+    from latte_amd.tta_step import FlatAdamEMA
+    a = [torch.nn.Parameter(torch.ones(8).cuda()), torch.nn.Parameter(torch.ones(3).cuda())]
+    e = [torch.ones(8).cuda(), torch.ones(3).cuda()]
+    opt = FlatAdamEMA(a, [torch.nn.Parameter(t) for t in e])
+    for p in a:
+        p.grad = torch.ones_like(p)
+    opt.gather_grads()
+    opt.step()
+    a[1].data = a[1].data.clone()            # what Module._apply does to every parameter
+    opt.gather_grads()
+    with pytest.raises(RuntimeError, match="no longer alias"):
+        opt.step()
+    with pytest.raises(ValueError, match="weight_decay"):
+        FlatAdamEMA([torch.nn.Parameter(torch.ones(4).cuda())], None, weight_decay=0.01, allow_missing_grads=True)

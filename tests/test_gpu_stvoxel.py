@@ -223,3 +223,76 @@ def test_class_masks_ignore_labels_outside_the_class_range():
     k_ref = ops.class_median_mask(ety[~odd].cuda(), lab[~odd].int().cuda(), 5, 0.9).cpu()
     k = ops.class_median_mask(ety.cuda(), lab_odd.int().cuda(), 5, 0.9).cpu()
     assert bool(k[odd].all()) and torch.equal(k[~odd], k_ref)
+
+
+def test_sort_segments_checks_the_key_bits_promise():
+    """ lt_sort_segments sorts key_bits + 1 bits only; an unmasked key at or beyond 2^key_bits (a stale key_bits,
+    an anchor id beyond its bits) would come out mis-sorted without a trace.  The device checks every key: LT_ERR_RANGE."""
+    from latte_amd import _lib, ops
+    g = torch.Generator().manual_seed(9)
+    keys = torch.randint(0, 1 << 20, (5000,), generator=g)
+    keys[::7] = torch.iinfo(torch.int64).max                      # masked elements are fine
+    se, inv, uk, seg = ops.sort_segments(keys.cuda(), 20)
+    want = torch.unique(keys[keys != torch.iinfo(torch.int64).max])
+    assert torch.equal(uk.cpu(), want)
+    bad = keys.clone()
+    bad[123] = (1 << 20) + 5
+    with pytest.raises(_lib.LatteHipError, match="key_bits"):
+        ops.sort_segments(bad.cuda(), 20)
+    ops.sort_segments(bad.cuda(), 21)                              # the same keys under an honest promise
+
+
+@pytest.mark.parametrize("case", ["tiny", "b1_32k", "nusc_cp05"])
+def test_cr_block_kernels_on_a_plain_dict_match_reference_golden(case):
+    """CR_Block (lt_cr_loss_fwd / lt_cr_loss_bwd) fed the way a caller outside this package would: a plain dict of per-anchor
+    LISTS (the reference's HR_Block output, here the golden arrays themselves) -- no pre-split tensors, no device offsets.
+    Loss against the reference's own CR_Block value; gradient against the oracle's autograd; every flag combination against
+    the oracle (ety_weight / conf_mask off, self_corr)."""
+    from latte_amd.hr_module import CR_Block
+    z, cfg, _ = load_hr_case(case)
+    tag = "32"
+    B = cfg["B"]
+    ac = [torch.from_numpy(z[f"{tag}_ac_logits_{i}"]).cuda().requires_grad_(True) for i in range(B)]
+    base = {
+        "ac_logits": ac, "tr_logits": [torch.from_numpy(z[f"{tag}_tr_logits_{i}"]).cuda() for i in range(B)],
+        "ac_voxels": [torch.from_numpy(z[f"{tag}_ac_voxels_{i}"]).cuda() for i in range(B)],
+        "tr_voxels": [torch.from_numpy(z[f"{tag}_tr_voxels_{i}"]).cuda() for i in range(B)],
+        "ac_p2v_indices": [torch.from_numpy(z[f"{tag}_ac_p2v_indices_{i}"]).cuda() for i in range(B)],
+        "tr_p2v_indices": [torch.from_numpy(z[f"{tag}_tr_p2v_indices_{i}"]).cuda() for i in range(B)],
+        "tr_conf_mask": torch.from_numpy(z[f"{tag}_tr_conf_mask"]).cuda(),
+        "ac_pc_ety": torch.from_numpy(z[f"{tag}_ac_pc_ety"]).cuda(), "tr_pc_ety": torch.from_numpy(z[f"{tag}_tr_pc_ety"]).cuda(),
+    }
+    loss = CR_Block(reduction="mean", conf_mask=True, ety_weight=True)(base)
+    want = float(z[f"{tag}_cr_loss"])
+    assert abs(float(loss.detach()) - want) < 1e-4 * abs(want)
+    loss.backward()
+    cpu = {k: ([t.detach().cpu() for t in v] if isinstance(v, list) else v.cpu()) for k, v in base.items()}
+    for kw in (dict(conf_mask=True, ety_weight=True), dict(conf_mask=False, ety_weight=True),
+               dict(conf_mask=True, ety_weight=False), dict(conf_mask=False, ety_weight=False)):
+        for self_corr in (False, True):
+            ac_ref = [t.clone().requires_grad_(True) for t in cpu["ac_logits"]]
+            ref = hr_ref.cr_forward(dict(cpu, ac_logits=ac_ref), self_corr=self_corr, **kw)
+            for t in ac:
+                t.grad = None
+            got = CR_Block(reduction="mean", **kw)(base, self_corr=self_corr)
+            assert abs(float(got.detach()) - float(ref.detach())) < 1e-4 * abs(float(ref.detach())), (kw, self_corr)
+            ref.backward()
+            (got * 2.0).backward()                       # the incoming gradient is used
+            for g, r in zip(ac, ac_ref):
+                assert float((g.grad.cpu() - 2.0 * r.grad).norm()) <= 1e-4 * float((2.0 * r.grad).norm()) + 1e-12, (kw, self_corr)
+    # zero probabilities (Q6): clamped to 1e-8 in the loss, no gradient through the clamped anchor entries
+    a0 = base["ac_logits"][0].detach().clone()
+    a0[:5, 0] = 0.0
+    a0.requires_grad_(True)
+    t0 = base["tr_logits"][0].clone()
+    t0[5:9, 1] = 0.0
+    d2 = dict(base, ac_logits=[a0] + base["ac_logits"][1:], tr_logits=[t0] + base["tr_logits"][1:])
+    cpu2 = {k: ([t.detach().cpu() for t in v] if isinstance(v, list) else v.cpu()) for k, v in d2.items()}
+    a0_ref = cpu2["ac_logits"][0].clone().requires_grad_(True)
+    ref = hr_ref.cr_forward(dict(cpu2, ac_logits=[a0_ref] + cpu2["ac_logits"][1:]), conf_mask=False, ety_weight=True)
+    got = CR_Block(reduction="mean", conf_mask=False, ety_weight=True)(d2)
+    assert np.isfinite(float(got.detach())) and abs(float(got.detach()) - float(ref.detach())) < 1e-4 * abs(float(ref.detach()))
+    got.backward()
+    ref.backward()
+    assert bool((a0.grad[:5, 0] == 0).all())
+    assert float((a0.grad.cpu() - a0_ref.grad).norm()) <= 1e-4 * float(a0_ref.grad.norm())

@@ -120,3 +120,41 @@ def test_cross_rank_batch_statistics_combine_exactly_gloo():
         out = mgr.dict()
         mp.spawn(_stats_worker, args=(2, _free_port(), out), nprocs=2, join=True)
         assert dict(out) == {0: True, 1: True}
+
+
+@pytest.mark.gpu
+def test_cross_rank_batchnorm_takes_part_with_zero_or_one_local_rows():
+    """ With cross-rank statistics every rank must issue the same sequence of collectives whatever its LOCAL row
+    count: a shard whose coarse level is empty (0 rows) or a single voxel (1 row) still calls the forward and backward
+    all-reduce (with zero sums) instead of raising / taking another path and leaving its peers waiting.  One process, a
+    one-rank gloo group: the collectives are issued and the results are the plain formulas."""
+    from latte_amd import functional as LF
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        C = 32
+        gamma = (0.5 + torch.rand(C)).cuda().requires_grad_(True)
+        beta = torch.randn(C).cuda().requires_grad_(True)
+        calls = []
+        real = LF._allreduce_small
+        LF._allreduce_small = lambda t, g: (calls.append(int(t.numel())), real(t, g))[1]
+        LF.SYNC_BN_GROUP = dist.group.WORLD
+        try:
+            for rows in (0, 1, 5):
+                x = torch.randn(rows, C).cuda().requires_grad_(True)
+                n0 = len(calls)
+                y = LF.batch_norm(x, gamma, beta, relu=True)
+                assert y.shape == x.shape and len(calls) == n0 + 1 and calls[-1] == 2 * C + 1     # forward collective
+                y.sum().backward()
+                assert len(calls) == n0 + 2 and calls[-1] == 2 * C                                   # backward collective
+                assert x.grad is not None and x.grad.shape == x.shape
+                if rows == 1:   # one row, one rank: xhat = 0 -> y = relu(beta)
+                    assert torch.allclose(y.detach()[0], torch.relu(beta.detach()), atol=1e-6)
+        finally:
+            LF.SYNC_BN_GROUP = None
+            LF._allreduce_small = real
+        with pytest.raises(ValueError):
+            LF.batch_norm(torch.randn(1, C).cuda(), gamma, beta)       # without the group: torch's refusal stays
+    finally:
+        dist.destroy_process_group()
