@@ -118,6 +118,15 @@ static inline LtStatsView lt_stats_view(void* mem, int64_t nb, int C) {
   return v;
 }
 
+// ---- internal (C++ linkage) pieces shared between translation units: not part of the C-ABI
+#ifdef __HIPCC__
+// lt_spconv_plan_fwd_stats that may pick any conv kernel; *nb = the number of partial rows [nb][2][Cout] it wrote
+int lt_spconv_plan_fwd_stats_nb(const float* in, const float* packed, const void* plan, float* out, int64_t Vin, int64_t Vout,
+                                int32_t Cin, int32_t Cout, int32_t K, void* stats_ws, int64_t* nb, hipStream_t stream);
+// lt_bn_finalize_sums over an explicit number of partial rows
+int lt_bn_finalize_sums_nb(void* stats_ws, int64_t nb, int64_t V, int32_t C, float* mean, float* var, hipStream_t stream);
+#endif
+
 // ---- device helpers -------------------------------------------------------
 #define LT_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
 

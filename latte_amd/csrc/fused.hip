@@ -16,9 +16,10 @@ extern "C" int lt_conv_bn_fwd(const float* in, const float* packed, const void* 
                               float* mean, float* var, hipStream_t stream) {
   LT_REQUIRE(Vout >= 2, LT_ERR_ARG, "lt_conv_bn_fwd: batch statistics need more than one row (Vout=%lld)", (long long)Vout);
   LT_REQUIRE(ws && ws_bytes >= lt_conv_bn_workspace_bytes(Vout, Cout), LT_ERR_WORKSPACE, "lt_conv_bn_fwd: workspace too small");
-  int rc = lt_spconv_plan_fwd_stats(in, packed, plan, conv_out, Vin, Vout, Cin, Cout, K, ws, stream);
+  int64_t nb = 0;   // partial rows the conv kernel that ran wrote (the kernel choice depends on the map, not only on the shape)
+  int rc = lt_spconv_plan_fwd_stats_nb(in, packed, plan, conv_out, Vin, Vout, Cin, Cout, K, ws, &nb, stream);
   if (rc) return rc;
-  rc = lt_bn_finalize_sums(ws, Vout, Cout, mean, var, stream);
+  rc = lt_bn_finalize_sums_nb(ws, nb, Vout, Cout, mean, var, stream);
   if (rc) return rc;
   return lt_bn_apply(conv_out, mean, var, gamma, beta, eps, residual, relu, y, Vout, Cout, stream);
 }

@@ -338,11 +338,14 @@ extern "C" int lt_bn_stats_static(const float* x, int64_t V, int32_t C, float* m
 }
 
 extern "C" int lt_bn_finalize_sums(void* stats_ws, int64_t V, int32_t C, float* mean, float* var, hipStream_t stream) {
+  return lt_bn_finalize_sums_nb(stats_ws, lt_spconv_stat_blocks(V, C), V, C, mean, var, stream);
+}
+
+int lt_bn_finalize_sums_nb(void* stats_ws, int64_t nb, int64_t V, int32_t C, float* mean, float* var, hipStream_t stream) {
   int rc = check_vc("lt_bn_finalize_sums", V, C);
   if (rc) return rc;
   LT_REQUIRE(C % 16 == 0, LT_ERR_ARG, "lt_bn_finalize_sums: C=%d must be a multiple of 16", C);
-  LT_REQUIRE(stats_ws && mean && var, LT_ERR_ARG, "lt_bn_finalize_sums: null pointer");
-  const int64_t nb = lt_spconv_stat_blocks(V, C);
+  LT_REQUIRE(stats_ws && mean && var && nb >= 1, LT_ERR_ARG, "lt_bn_finalize_sums: null pointer");
   LtStatsView sv = lt_stats_view(stats_ws, nb, C);
   if (nb <= 2048) {
     hipLaunchKernelGGL((k_stats_reduce<float, true>), dim3(C / 16, 1), dim3(1024), 0, stream, sv.partial, nb, V, C, sv.stage,

@@ -26,12 +26,9 @@
 #include "common.h"
 #include <cstdlib>
 #include "../../include/latte_hip.h"
+#include "spconv_args.h"
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-#define LT_TM 64        // output rows per workgroup
-#define LT_KMAX 32      // max kernel volume held in LDS (27 used)
-#define LT_JB 4         // 16-channel groups staged per step
+#define LT_JB 4         // 16-channel groups staged per step (LT_TM, LT_KMAX: spconv_args.h)
 
 // ---------------------------------------------------------------- weight packing
 // vec layout  (Cin_e % 16 == 0): packed[(((k*J + j)*NTt + nt)*64 + lane)*4 + t] = E_k[16j + 4q + t][16nt + n]
@@ -283,21 +280,7 @@ __global__ __launch_bounds__(256) void k_spconv_scalar(ConvArgs a) {
 //    the gathered A rows of the next stage are prefetched into a second register set at the same point;
 //  * a stage is UB "slabs" (= one offset x one 16-channel group of Cin), so narrow layers still get >= 16 KiB stages.
 // Every output element is still one k-ascending, channel-ascending fmaf chain -> bitwise equal to k_spconv_vec.
-struct PlanArgs {
-  const float* in;
-  const float* packed;
-  const int* tnbr;                    // [T][K][64]
-  const unsigned long long* tmask;    // [T][K]
-  const int* order;                   // [Vout]
-  const int* torder;                  // [T] tiles by descending work
-  float* out;
-  int Vin, Vout, Cin, Cout, K;
-  float* partial;                     // optional [row workgroups][2][Cout]: per-workgroup column sums of out and out^2
-  int gx;                             // split-k: row workgroups (the grid is 1-D there, see the XCD mapping)
-  int swz;                            // split-k: XCD-aware workgroup mapping on
-  int dbg;                            // diagnostics (wrong results): 1 = weights of slab 0 only, 2 = rows 0..15 only, 4 = stamps, 8 / 16 = no A / B loads (split-j)
-  long long* stamps;                  // [workgroup][wave][8]
-};
+// PlanArgs: spconv_args.h (shared with spconv_ls.hip)
 
 // events of the armed conv launch timer for the launch being issued (null otherwise): the conv kernels are launched
 // with hipExtLaunchKernelGGL, which stamps them with the dispatch's own begin / end times (no extra barrier packets)
@@ -305,6 +288,10 @@ struct PlanArgs {
 static thread_local hipEvent_t g_conv_ev0 = nullptr, g_conv_ev1 = nullptr;
 #define LT_CONV_LAUNCH(kernel, grid, block, stream, ...) \
   hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, g_conv_ev0, g_conv_ev1, 0, __VA_ARGS__)
+void lt_conv_launch_events(hipEvent_t* e0, hipEvent_t* e1) {
+  *e0 = g_conv_ev0;
+  *e1 = g_conv_ev1;
+}
 
 // diagnostics: per-wave time stamps of k_spconv_rf (variant bit dbg & 4); buffer set by lt_conv_debug_stamps
 static long long* g_conv_stamps = nullptr;
@@ -1644,24 +1631,55 @@ extern "C" int64_t lt_spconv_stats_bytes(int64_t Vout, int32_t Cout) {
 
 static int spconv_plan_impl(const float* in, const float* packed, const void* plan, float* out, int64_t Vin,
                             int64_t Vout, int32_t Cin, int32_t Cout, int32_t K, int32_t variant, float* partial,
-                            hipStream_t stream);
+                            int64_t* nb_out, bool allow_ls, hipStream_t stream);
 
 extern "C" int lt_spconv_plan_fwd_v(const float* in, const float* packed, const void* plan, float* out, int64_t Vin,
                                     int64_t Vout, int32_t Cin, int32_t Cout, int32_t K, int32_t variant,
                                     hipStream_t stream) {
-  return spconv_plan_impl(in, packed, plan, out, Vin, Vout, Cin, Cout, K, variant, nullptr, stream);
+  return spconv_plan_impl(in, packed, plan, out, Vin, Vout, Cin, Cout, K, variant, nullptr, nullptr, true, stream);
 }
 
+// The public pair lt_spconv_plan_fwd_stats / lt_bn_finalize_sums agrees on the number of partial rows through
+// lt_spconv_stat_blocks(Vout, Cout), a function of the output shape only -- so it stays on the general kernels.  The
+// composites (fused.hip) use lt_spconv_plan_fwd_stats_nb, which may pick the LDS-staged kernel and REPORTS how many
+// partial rows it wrote.
 extern "C" int lt_spconv_plan_fwd_stats(const float* in, const float* packed, const void* plan, float* out, int64_t Vin,
                                         int64_t Vout, int32_t Cin, int32_t Cout, int32_t K, void* stats_ws,
                                         hipStream_t stream) {
   LT_REQUIRE(stats_ws, LT_ERR_ARG, "lt_spconv_plan_fwd_stats: stats_ws is null");
-  return spconv_plan_impl(in, packed, plan, out, Vin, Vout, Cin, Cout, K, 0, (float*)stats_ws, stream);
+  return spconv_plan_impl(in, packed, plan, out, Vin, Vout, Cin, Cout, K, 0, (float*)stats_ws, nullptr, false, stream);
+}
+
+int lt_spconv_plan_fwd_stats_nb(const float* in, const float* packed, const void* plan, float* out, int64_t Vin, int64_t Vout,
+                                int32_t Cin, int32_t Cout, int32_t K, void* stats_ws, int64_t* nb, hipStream_t stream) {
+  LT_REQUIRE(stats_ws && nb, LT_ERR_ARG, "lt_spconv_plan_fwd_stats_nb: null pointer");
+  return spconv_plan_impl(in, packed, plan, out, Vin, Vout, Cin, Cout, K, 0, (float*)stats_ws, nb, true, stream);
+}
+
+// Which convs take the LDS-staged kernel (spconv_ls.hip) by default: maps of a 2^3 kernel in the direction where every
+// output row has ONE pair (more output rows than input rows: transposed conv forward, strided conv backward-input).
+// Measured at the a2d2_kitti_128k sizes (tools/k8_bench.py, profiles/diag/r03_k8_bench.txt): alone it wins on the finest
+// levels (96 -> 96 channels at 310 k rows 75 vs 97 us, 32 -> 32 19 vs 25 us) and loses up to 15 % on the coarse ones; inside
+// the step, where the general kernel's operand loads compete with everything else for the address path, taking it for
+// all of them is the fastest (31.63 -> 31.49 ms same box).  In the other direction (2-3 pairs per row, several offsets
+// per tile) it re-stages the weights per (tile, offset) and loses by 2x: never.  LT_CONV_LS=0 switches it off (A/B).
+static bool conv_ls_default(int64_t Vin, int64_t Vout, int Cin, int Cout, int K) {
+  static const int mode = [] {
+    const char* e = getenv("LT_CONV_LS");
+    return e ? atoi(e) : 1;
+  }();
+  if (mode == 0 || K > 8 || K < 2 || Vout <= Vin || g_conv_precision != 0) return false;
+  return lt_spconv_ls_supported(Vin, Vout, Cin, Cout, K);
 }
 
 static int spconv_plan_impl(const float* in, const float* packed, const void* plan, float* out, int64_t Vin,
                             int64_t Vout, int32_t Cin, int32_t Cout, int32_t K, int32_t variant, float* partial,
-                            hipStream_t stream) {
+                            int64_t* nb_out, bool allow_ls, hipStream_t stream) {
+  if (nb_out) *nb_out = lt_spconv_stat_blocks(Vout, Cout);
+  if (variant == 5001) {   // A/B measurements: the general default kernel where the default would be the LDS-staged one
+    variant = 0;
+    allow_ls = false;
+  }
   LT_REQUIRE(Vin >= 0 && Vout >= 0 && Vin < INT32_MAX && Vout < INT32_MAX, LT_ERR_RANGE, "lt_spconv_plan_fwd: bad row counts");
   LT_REQUIRE(K >= 1 && K <= LT_KMAX, LT_ERR_ARG, "lt_spconv_plan_fwd: kernel volume %d not in [1,%d]", K, LT_KMAX);
   LT_REQUIRE(Cin >= 16 && Cin % 16 == 0, LT_ERR_ARG, "lt_spconv_plan_fwd: Cin=%d must be a multiple of 16", Cin);
@@ -1673,7 +1691,7 @@ static int spconv_plan_impl(const float* in, const float* packed, const void* pl
   PlanArgs a{in, packed, pv.tnbr, pv.tmask, pv.order, pv.torder, out, (int)Vin, (int)Vout, Cin, Cout, K, partial, 0, 1, 0, nullptr};
   LtConvTimerScope timed(stream, Cin, Cout, K, Vout);
   const int ntt = Cout / 16;
-  LT_REQUIRE(!(partial && variant != 0), LT_ERR_ARG, "lt_spconv_plan_fwd: statistics need the default variant");
+  LT_REQUIRE(!(partial && variant != 0 && variant != 5000), LT_ERR_ARG, "lt_spconv_plan_fwd: statistics need the default variant");
   if (conv_uses_bf16(Cin, Cout) && !(variant >= 3000 && variant < 4000)) {
     // The caller packed this conv's weights as the bf16 hi|lo image (same rule, lt_conv_uses_bf16): only the bf16x3 kernel
     // may read them.  What it cannot run is an error, never a silent fall-through to an fp32 kernel over a bf16 image.
@@ -1689,6 +1707,18 @@ static int spconv_plan_impl(const float* in, const float* packed, const void* pl
     const int jp = Cin / 32, ntw = bf_default_ntw(Cout), w = jp % 2 == 0 ? 2 : 1;
     LT_REQUIRE(bf_supported(Cin, Cout, 2, ntw, w), LT_ERR_ARG, "lt_spconv_plan_fwd: no bf16x3 shape for Cin=%d Cout=%d", Cin, Cout);
     return launch_bf(a, 2, ntw, w, stream);
+  }
+  if (variant > 5001 && variant < 5100) {   // 5010 + dbg bits: diagnostics of the LDS-staged kernel (wrong results)
+    a.dbg = variant - 5010;
+    if (a.dbg & 4) a.stamps = g_conv_stamps;   // the caller sized the buffer for [workgroups][8 waves][8] words
+    variant = 5000;
+  }
+  if (variant == 5000 || (variant == 0 && allow_ls && conv_ls_default(Vin, Vout, Cin, Cout, K))) {
+    LT_REQUIRE(lt_spconv_ls_supported(Vin, Vout, Cin, Cout, K), LT_ERR_ARG,
+               "lt_spconv_plan_fwd_v: the LDS-staged kernel does not take Cin=%d Cout=%d K=%d at these sizes", Cin, Cout, K);
+    if (nb_out) *nb_out = lt_spconv_ls_stat_blocks(Vout, Cin, Cout, K);
+    LT_REQUIRE(!partial || nb_out, LT_ERR_ARG, "lt_spconv_plan_fwd: the LDS-staged kernel with statistics needs nb_out");
+    return lt_spconv_ls_launch(a, stream);
   }
   if (variant == 0) {
     const LtConvShape sh = conv_default_shape(Vin, Vout, Cin, Cout, K);

@@ -232,7 +232,8 @@ def test_spconv_plan_is_bitwise_equal_to_table_kernel(scans_small, cin, cout, ks
     pw = ops.pack_weights(w, 0)
     a = ops.spconv(feats, pw, resd, cout)
     plan = ops.kmap_plan(resd)
-    variants = [1] + [100 * sr + ntw for sr in (1, 2, 4, 8) for ntw in (1, 2, 4) if (cout // 16) % ntw == 0]
+    # 5000 = the LDS-staged-weights kernel (spconv_ls.hip; default for the 2^3 maps): one chain per output, too
+    variants = [1, 5000] + [100 * sr + ntw for sr in (1, 2, 4, 8) for ntw in (1, 2, 4) if (cout // 16) % ntw == 0]
     for v in variants:
         b = ops.spconv_plan(feats, pw, plan, K, resd.shape[1], cout, variant=v)
         assert torch.equal(a, b), v
@@ -246,7 +247,7 @@ def test_spconv_plan_is_bitwise_equal_to_table_kernel(scans_small, cin, cout, ks
     pwt = ops.pack_weights(w, 1)
     a = ops.spconv(gout, pwt, rev, cin)
     rplan = ops.kmap_plan(rev)
-    for v in [1] + [100 * sr + ntw for sr in (1, 2, 4, 8) for ntw in (1, 2, 4) if (cin // 16) % ntw == 0]:
+    for v in [1, 5000] + [100 * sr + ntw for sr in (1, 2, 4, 8) for ntw in (1, 2, 4) if (cin // 16) % ntw == 0]:
         b = ops.spconv_plan(gout, pwt, rplan, K, c.shape[0], cin, variant=v)
         assert torch.equal(a, b), v
     for v in [0] + _sk_variants(cin):
@@ -269,7 +270,7 @@ def test_spconv_plan_empty_rows_and_ragged_tail():
     nd = nbr.cuda()
     a = ops.spconv(feats, pw, nd, C)
     plan = ops.kmap_plan(nd)
-    for v in (1, 101, 102, 201, 202, 401, 402, 801, 802):
+    for v in (1, 101, 102, 201, 202, 401, 402, 801, 802, 5000):
         b = ops.spconv_plan(feats, pw, plan, K, V, C, variant=v)
         assert torch.equal(a, b), v
         assert float(b[5].abs().max()) == 0.0
