@@ -12,9 +12,12 @@ Workloads (latte_amd/synth.py restates BASELINE.json's configs):
   N = 1   a2d2_kitti_128k  BASELINE configs[2], the largest single-GPU config: 6 x 131 072-point scans, 5 cm input voxels,
           ST voxels 0.1 m / R 40 m / 3-frame window, 10 classes, SPVCNN cr = 1.0, fp32.  configs[0] / configs[1]
           (synthia_kitti_32k, nuscenes_34k_w5) are measured right after it and reported in `other_workloads`.
-  N > 1   multiseq_64      BASELINE configs[3]: 64 scans per step = 8 sequences x 8 frames of 34 816 points, sequences
-          dealt to the ranks (4/2/1 per GPU at N = 2/4/8), STRONG scaling: total work fixed, no data-path collective, one
-          flat all-reduce of the 13 248 BatchNorm grads.  Its one-GPU base: `--gpus 1 --workload multiseq_64`.
+  N > 1   the SAME workload per GPU (weak scaling, what `value` and the driver's efficiency are computed on): every rank
+          owns its own sequence of 6 a2d2 scans -- independent sequences shard across the GPUs with no data-path
+          collective; the only exchange is one flat RCCL all-reduce of the 13 248 BatchNorm grads per step.
+          Then, in the extra object `strong_scaling_multiseq_64`, BASELINE configs[3]: 64 scans per step = 8 sequences x 8
+          frames of 34 816 points, whole sequences dealt to the ranks (4/2/1 per GPU at N = 2/4/8), total work fixed, with
+          rank 0's one-GPU time of the same 64-scan step measured in the same run.
   --workload conv_1m       BASELINE configs[4]: 3^3 conv over >= 1 M voxels, C = 16..256, plus one U-Net forward over them.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
@@ -49,8 +52,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default=None, help="default: a2d2_kitti_128k at --gpus 1, multiseq_64 (sequences "
-                    "sharded, strong scaling) at --gpus N > 1; conv_1m = the sparse-conv micro-benchmark")
+    ap.add_argument("--workload", default=None, help="default: a2d2_kitti_128k (N > 1: per GPU, weak scaling; the strong-scaling "
+                    "multiseq_64 run follows as an extra object); multiseq_64 = 64 scans dealt to the ranks by sequence; "
+                    "conv_1m = the sparse-conv micro-benchmark")
     ap.add_argument("--cr", type=float, default=1.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scans", type=int, default=None, help="scans in the CPU-oracle sample (default: sized to ~20 s)")
@@ -69,7 +73,7 @@ def parse():
     ap.add_argument("--conv-precision", default="f32", choices=["f32", "bf16x3"], help="arithmetic of the sparse convs: fp32 "
                     "MFMA (default, the headline) or the opt-in bf16x3 split-precision kernel (lt_conv_set_precision)")
     ap.add_argument("--no-bf16x3-line", action="store_true", help="skip the extra bf16x3 measurement of the default run")
-    ap.add_argument("--no-weak-line", action="store_true", help="N > 1: skip the weak-scaling run of the N = 1 headline workload")
+    ap.add_argument("--no-strong-line", action="store_true", help="N > 1: skip the strong-scaling run of multiseq_64 (configs[3])")
     ap.add_argument("--no-scaling-base", action="store_true", help="N > 1: skip rank 0's one-GPU run of the whole 64-scan step")
     ap.add_argument("--emulate-shard", type=int, default=0, help="diagnostic, one GPU: time the step of rank 0's shard of "
                     "multiseq_64 split over this many ranks (what one rank of an N-GPU run computes; no collective)")
@@ -480,7 +484,7 @@ def main():
 
     from latte_amd import ops as _ops
     _ops.set_conv_precision(args.conv_precision)
-    name = args.workload or ("a2d2_kitti_128k" if world == 1 else "multiseq_64")
+    name = args.workload or "a2d2_kitti_128k"
     w = synth.workload(name)
     scaling = "weak"
     total_scans = w["B"] * world
@@ -510,20 +514,24 @@ def main():
     r = time_steps(step, batch, args, world, dev, backend, fwd_only=args.fwd_only, kernel_events=not args.no_kernel_events)
     dt = r["dt"]
 
-    # N > 1, default workload: after the strong-scaling run every rank also times the N = 1 headline workload on its own 6
-    # scans (weak scaling: value / (N x the one-GPU headline) is the efficiency against the driver's N = 1 line)
-    weak = None
-    if world > 1 and args.workload is None and not args.no_weak_line and not args.fwd_only:
-        ww = synth.workload("a2d2_kitti_128k")
-        torch.manual_seed(1)
-        wm = Net3DSeg(ww["C"], True, "SPVCNN", {"cr": args.cr}).to(dev)
-        wstep = LatteStep(wm, ww["C"], hr_cfg_of(ww), process_group=pg, side_stream=not args.no_side_stream)
-        wb = build_batch(ww, device=dev, scan_offset=shard_scan_offset(rank, ww["B"]), seed=rank)
-        wr = time_steps(wstep, wb, args, world, dev, backend, steps=max(5, args.steps // 2), warmup=2, kernel_events=False)
-        weak = {"workload": "a2d2_kitti_128k", "scaling": "weak", "scans_per_gpu": ww["B"], "n_gpus": world,
-                "value": world * ww["B"] * ww["n"] * wr["steps"] / wr["dt"], "unit": "points/s",
-                "ms_per_step": round(1e3 * wr["dt"] / wr["steps"], 3), "steps": wr["steps"]}
-        del wm, wstep, wb
+    # N > 1, default workload: after the weak-scaling headline every rank takes its share of BASELINE configs[3] -- ONE step of
+    # 64 scans = 8 sequences x 8 frames, whole sequences dealt to the ranks (strong scaling: total work fixed)
+    strong = None
+    sw = None
+    if world > 1 and args.workload is None and not args.no_strong_line and not args.fwd_only:
+        sw = synth.workload("multiseq_64")
+        n_seq = sw["B"] // sw["seq_len"]
+        if world <= n_seq:
+            s0, ns = shard_sequences(n_seq, world, rank)
+            torch.manual_seed(1)
+            sm = Net3DSeg(sw["C"], True, "SPVCNN", {"cr": args.cr}).to(dev)
+            sstep = LatteStep(sm, sw["C"], hr_cfg_of(sw), process_group=pg, side_stream=not args.no_side_stream)
+            sb = build_batch(dict(sw, B=ns * sw["seq_len"]), device=dev, scan_offset=s0 * sw["seq_len"], seed=rank)
+            sr = time_steps(sstep, sb, args, world, dev, backend, steps=max(5, args.steps // 2), warmup=2, kernel_events=False)
+            strong = {"workload": "multiseq_64", "scaling": "strong", "scans_per_step": sw["B"], "scans_per_gpu": ns * sw["seq_len"],
+                      "n_gpus": world, "value": sw["B"] * sw["n"] * sr["steps"] / sr["dt"], "unit": "points/s",
+                      "ms_per_step": round(1e3 * sr["dt"] / sr["steps"], 3), "steps": sr["steps"]}
+            del sm, sstep, sb
 
     if rank == 0:
         roof = None
@@ -605,18 +613,17 @@ def main():
                         "what": "timed region starts at raw host points (pinned): H2D + input voxelization "
                                 "(quantize_scan_gpu) + collate run on the side stream one iteration ahead, then the same step; "
                                 "never the headline `value` (that one starts with the inputs resident in HBM)"}
-        base1 = None
-        if world > 1 and scaling == "strong" and not args.no_scaling_base:
+        if strong is not None and not args.no_scaling_base:
             # the strong-scaling base in the SAME run: rank 0 alone takes the whole 64-scan step (the other ranks wait at
-            # the barrier below), so value / base value is the speed-up over one GPU on identical work
+            # the barrier below), so the speed-up over one GPU on identical work is in the same JSON line
             torch.manual_seed(1)
-            m1 = Net3DSeg(w["C"], True, "SPVCNN", {"cr": args.cr}).to(dev)
-            s1 = LatteStep(m1, w["C"], hr_cfg_of(w), side_stream=not args.no_side_stream)
-            b1 = build_batch(w, device=dev, scan_offset=0, seed=0)
+            m1 = Net3DSeg(sw["C"], True, "SPVCNN", {"cr": args.cr}).to(dev)
+            s1 = LatteStep(m1, sw["C"], hr_cfg_of(sw), side_stream=not args.no_side_stream)
+            b1 = build_batch(sw, device=dev, scan_offset=0, seed=0)
             r1 = time_steps(s1, b1, args, 1, dev, backend, steps=max(4, args.steps // 2), warmup=2, kernel_events=False)
-            base1 = {"n_gpus": 1, "workload": name, "ms_per_step": round(1e3 * r1["dt"] / r1["steps"], 3),
-                     "value": n_points_total * r1["steps"] / r1["dt"], "unit": "points/s", "steps": r1["steps"],
-                     "speedup_of_this_run": round((r1["dt"] / r1["steps"]) / (dt / args.steps), 3)}
+            strong["one_gpu_base"] = {"ms_per_step": round(1e3 * r1["dt"] / r1["steps"], 3),
+                                      "value": sw["B"] * sw["n"] * r1["steps"] / r1["dt"], "unit": "points/s", "steps": r1["steps"]}
+            strong["speedup_over_one_gpu"] = round(strong["one_gpu_base"]["ms_per_step"] / strong["ms_per_step"], 3)
             del m1, s1, b1
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
@@ -632,8 +639,7 @@ def main():
                        "batchnorm_statistics": "cross-rank (exact)" if (args.sync_bn and world > 1) else "per GPU",
                        "parallelism": f"dp{world} (whole sequences per rank, no data-path collective"
                                       + (", one flat RCCL all-reduce of the BatchNorm grads)" if world > 1 else ")"),
-                       **({"strong_scaling_base": "python bench.py --gpus 1 --workload multiseq_64"}
-                          if scaling == "strong" else {})},
+                       },
             "host_issue_ms_per_step": round(1e3 * r["dt_host"] / args.steps, 3),
             "roofline": roof, "cpu_baseline": cpu,
         }
@@ -643,10 +649,8 @@ def main():
             out["bf16x3_mode"] = bf
         if from_raw is not None:
             out["from_raw"] = from_raw
-        if base1 is not None:
-            out["strong_scaling_base_measured"] = base1
-        if weak is not None:
-            out["weak_scaling_a2d2"] = weak
+        if strong is not None:
+            out["strong_scaling_multiseq_64"] = strong
         out["config"]["conv_precision"] = args.conv_precision
         if force_pg:
             out["config"]["rehearsal"] = f"one-rank {backend} process group, gradient all-reduce issued every step"

@@ -408,6 +408,18 @@ class _ConvBN(Function):
 
 def conv_bn(feats, weight, gamma, beta, kmap: KernelMap, transposed=False, residual=None, relu=False, eps=1e-5,
             wcache=None):
+    if not torch.is_grad_enabled():
+        # the teacher forward (latte/tta/tools/latte.py:156-159 runs it under no_grad): no autograd node, nothing saved,
+        # BatchNorm applied in place on the conv output
+        w = weight if weight.dim() == 3 else weight.unsqueeze(0)
+        if ops.CONV_PAIRS is not None:
+            if kmap._npairs is None:
+                kmap._npairs = (kmap.results >= 0).sum()
+            ops.CONV_PAIRS.append(kmap._npairs)
+        n_out = kmap.n_in if transposed else kmap.n_out
+        plan = kmap.reverse_plan() if transposed else kmap.plan()
+        return ops.conv_bn_fwd(feats.contiguous(), _packed(weight, 0, wcache), plan, kmap.K, n_out, w.shape[2], gamma.detach(),
+                               beta.detach(), float(eps), residual, bool(relu), keep_conv_out=False)[1]
     return _ConvBN.apply(feats.contiguous(), weight, gamma, beta, residual, kmap, bool(transposed), bool(relu),
                          float(eps), wcache)
 

@@ -39,6 +39,35 @@ def _ws(nbytes: int, device) -> torch.Tensor:
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
 
+# Transient workspaces of the hot per-layer ops (BatchNorm partial sums, conv statistics): their contents live inside ONE
+# library call, and calls on one stream execute in order, so a buffer per (thread, stream) is reused by every call instead
+# of a fresh torch.empty each (3.5 us of host time per allocation, ~300 of them per step).  Never for outputs or for
+# anything a later call reads (tables, plans).
+_SCRATCH: dict = {}
+_WS_BYTES: dict = {}
+
+
+def _scratch(nbytes: int, device) -> torch.Tensor:
+    import threading
+    idx = device.index if device.index is not None else torch._C._cuda_getDevice()
+    key = (threading.get_ident(), torch._C._cuda_getCurrentRawStream(idx), idx)
+    t = _SCRATCH.get(key)
+    if t is None or t.numel() < nbytes:
+        t = _SCRATCH[key] = torch.empty(max(int(nbytes) * 3 // 2, 1 << 20), dtype=torch.uint8, device=device)
+    return t
+
+
+def _ws_bytes(fn_name: str, *args) -> int:
+    """cached *_workspace_bytes query (a ctypes round trip per layer otherwise)"""
+    key = (fn_name,) + args
+    v = _WS_BYTES.get(key)
+    if v is None:
+        if len(_WS_BYTES) > 4096:
+            _WS_BYTES.clear()
+        v = _WS_BYTES[key] = int(getattr(_lib.load(), fn_name)(*args))
+    return v
+
+
 # ------------------------------------------------------------------ hashing
 def sphash(coords: torch.Tensor, offsets: torch.Tensor | None = None) -> torch.Tensor:
     coords = _chk(coords, torch.int32, "sphash coords")
@@ -303,10 +332,9 @@ def spconv_plan(feats: torch.Tensor, packed: torch.Tensor, plan: torch.Tensor, K
 def bn_stats(x: torch.Tensor):
     x = _chk(x, torch.float32, "bn_stats x")
     V, C = x.shape
-    lib = _lib.load()
-    ws = _ws(lib.lt_bn_workspace_bytes(V, C), x.device)
-    mean = torch.empty(C, dtype=torch.float32, device=x.device)
-    var = torch.empty(C, dtype=torch.float32, device=x.device)
+    ws = _scratch(_ws_bytes("lt_bn_workspace_bytes", V, C), x.device)
+    mv = torch.empty((2, C), dtype=torch.float32, device=x.device)
+    mean, var = mv[0], mv[1]
     _lib.call("lt_bn_stats", _p(x), V, C, _p(ws), ws.numel(), _p(mean), _p(var), _stream())
     return mean, var
 
@@ -345,10 +373,9 @@ def bn_bwd(dy, x, y, mean, var, gamma, eps: float, relu: bool, need_dx=True, nee
     dy = _chk(dy, torch.float32, "bn_bwd dy")
     x = _chk(x, torch.float32, "bn_bwd x")
     V, C = x.shape
-    lib = _lib.load()
-    ws = _ws(lib.lt_bn_workspace_bytes(V, C), x.device)
-    sum_g = torch.empty(C, dtype=torch.float32, device=x.device)
-    sum_gx = torch.empty(C, dtype=torch.float32, device=x.device)
+    ws = _scratch(_ws_bytes("lt_bn_workspace_bytes", V, C), x.device)
+    sums = torch.empty((2, C), dtype=torch.float32, device=x.device)
+    sum_g, sum_gx = sums[0], sums[1]
     mode = _relu_mode(relu, y, beta)
     yp = _p(y) if mode == 1 else None
     gp = _p(_chk(gamma.detach(), torch.float32, "gamma"))
@@ -655,15 +682,16 @@ def cr_loss_bwd(ac, tr, row_w, keep, row_anchor, stats, B: int, gloss):
 
 
 # ------------------------------------------------------------------ conv -> BN [+ residual] [+ ReLU] composites
-def conv_bn_fwd(feats, packed, plan, K: int, Vout: int, cout: int, gamma, beta, eps: float, residual, relu: bool):
-    """-> (conv_out, y, mean, var).  One host call (lt_conv_bn_fwd): conv with statistics epilogue, finalize, BN apply."""
+def conv_bn_fwd(feats, packed, plan, K: int, Vout: int, cout: int, gamma, beta, eps: float, residual, relu: bool,
+                keep_conv_out: bool = True):
+    """-> (conv_out, y, mean, var).  One host call (lt_conv_bn_fwd): conv with statistics epilogue, finalize, BN apply.
+    keep_conv_out False (no backward will come): BatchNorm is applied in place, conv_out is y."""
     Vin, Cin = feats.shape
     dev = feats.device
-    lib = _lib.load()
     conv_out = torch.empty((Vout, cout), dtype=torch.float32, device=dev)
-    y = torch.empty((Vout, cout), dtype=torch.float32, device=dev)
+    y = torch.empty((Vout, cout), dtype=torch.float32, device=dev) if keep_conv_out else conv_out
     stats = torch.empty((2, cout), dtype=torch.float32, device=dev)
-    ws = _ws(lib.lt_conv_bn_workspace_bytes(Vout, cout), dev)
+    ws = _scratch(_ws_bytes("lt_conv_bn_workspace_bytes", Vout, cout), dev)
     mean, var = stats[0], stats[1]
     _lib.call("lt_conv_bn_fwd", _p(feats), _p(packed), _p(plan), Vin, Vout, Cin, int(cout), K, _p(gamma), _p(beta),
               float(eps), _p(residual), int(relu), _p(ws), ws.numel(), _p(conv_out), _p(y), _p(mean), _p(var), _stream())
@@ -676,8 +704,7 @@ def conv_bn_bwd(dy, conv_out, y, mean, var, gamma, eps: float, relu: bool, need_
     ReLU mask is rebuilt from conv_out (needs beta; the forward added no residual)."""
     Vout, cout = conv_out.shape
     dev = conv_out.device
-    lib = _lib.load()
-    ws = _ws(lib.lt_conv_bn_workspace_bytes(Vout, cout), dev)
+    ws = _scratch(_ws_bytes("lt_conv_bn_workspace_bytes", Vout, cout), dev)
     dgb = torch.empty((2, cout), dtype=torch.float32, device=dev)
     dgamma, dbeta = dgb[0], dgb[1]
     dres = torch.empty_like(conv_out) if need_dres else None

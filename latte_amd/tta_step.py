@@ -405,6 +405,13 @@ class LatteStep:
         self.hr_side_stream = side_stream
         self._side = None
         self._pre = None   # (batch, tables, geo23, geo32) built ahead by prefetch()
+        if self.hr_side_stream:
+            # two Python threads feed the GPU (this one and the prefetch helper): hand the GIL over every 0.5 ms instead of
+            # CPython's default 5 ms, so neither stalls the other's launch stream for long
+            import sys
+            want = float(__import__("os").environ.get("LATTE_DIAG_SWITCH_INTERVAL", "5e-4"))
+            if sys.getswitchinterval() > want:
+                sys.setswitchinterval(want)
         self._inflight: List = []   # end-of-step events of the iterations the GPU may still be working on
         if self.hr_side_stream and self.params[0].is_cuda:
             ensure_side_stream(self.params[0].device)   # created now, not inside the first step (deterministic creation order)
