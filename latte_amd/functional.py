@@ -362,6 +362,9 @@ class _BatchNorm(Function):
         return dx, dgamma, dbeta, dres, None, None, None, None
 
 
+_DIAG_NO_APPLY = False   # diagnostics (spvcnn._DIAG_SKIP_FIRST_APPLY): composites skip the BatchNorm apply pass, WRONG results
+
+
 class _ConvBN(Function):
     """y = relu(bn(conv(feats)) + residual) as ONE autograd node over the composite entry points lt_conv_bn_fwd/bwd
     (frozen conv kernel: the norm-only TTA configuration; anything else takes the unfused ops)."""

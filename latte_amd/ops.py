@@ -693,6 +693,12 @@ def conv_bn_fwd(feats, packed, plan, K: int, Vout: int, cout: int, gamma, beta, 
     stats = torch.empty((2, cout), dtype=torch.float32, device=dev)
     ws = _scratch(_ws_bytes("lt_conv_bn_workspace_bytes", Vout, cout), dev)
     mean, var = stats[0], stats[1]
+    from . import functional as LF
+    if LF._DIAG_NO_APPLY:   # diagnostics: conv + statistics, no apply pass (y = the raw conv output)
+        _lib.call("lt_spconv_plan_fwd_stats", _p(feats), _p(packed), _p(plan), _p(conv_out), Vin, Vout, Cin, int(cout), K, _p(ws),
+                  _stream())
+        _lib.call("lt_bn_finalize_sums", _p(ws), Vout, int(cout), _p(mean), _p(var), _stream())
+        return conv_out, conv_out, mean, var
     _lib.call("lt_conv_bn_fwd", _p(feats), _p(packed), _p(plan), Vin, Vout, Cin, int(cout), K, _p(gamma), _p(beta),
               float(eps), _p(residual), int(relu), _p(ws), ws.numel(), _p(conv_out), _p(y), _p(mean), _p(var), _stream())
     return conv_out, y, mean, var

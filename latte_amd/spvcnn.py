@@ -49,6 +49,26 @@ def _conv_bn_impl(seq, x: SparseTensor, i: int, relu: bool, residual=None) -> Sp
     return y
 
 
+# diagnostics (tools only, WRONG results): the first conv of every residual block runs conv + statistics but NOT the BatchNorm
+# apply pass -- what a consumer that normalises on load would leave of that layer: the measured upper bound of that fusion
+_DIAG_SKIP_FIRST_APPLY = bool(__import__("os").environ.get("LATTE_DIAG_SKIP_FIRST_APPLY"))
+
+
+def _conv_stats_only(seq, x: SparseTensor) -> SparseTensor:
+    from . import functional as LF
+    conv, bn = seq[0], seq[1]
+    kmap, out_coords = spnn.build_kernel_map(x, conv.kernel_size, conv.stride, conv.dilation)
+    LF._DIAG_NO_APPLY = True
+    try:
+        out = LF.conv_bn(x.feats, conv.kernel, bn.weight, bn.bias, kmap, False, residual=None, relu=True, eps=bn.eps,
+                         wcache=conv._packed_cache)
+    finally:
+        LF._DIAG_NO_APPLY = False
+    y = SparseTensor(out, out_coords, x.stride)
+    y.cmaps, y.kmaps = x.cmaps, x.kmaps
+    return y
+
+
 class BasicConvolutionBlock(nn.Module):
     def __init__(self, inc, outc, ks=3, stride=1, dilation=1):
         super().__init__()
@@ -88,7 +108,10 @@ class ResidualBlock(nn.Module):
             shortcut = x.feats
         else:
             shortcut = _conv_bn(self.downsample, x, 0, relu=False).feats
-        y = _conv_bn(self.net, x, 0, relu=True)
+        if _DIAG_SKIP_FIRST_APPLY and x.feats.is_cuda:
+            y = _conv_stats_only(self.net, x)   # upper bound of what normalise-on-load could save (WRONG results)
+        else:
+            y = _conv_bn(self.net, x, 0, relu=True)
         # relu(bn(conv(y)) + shortcut) in one kernel
         return _conv_bn(self.net, y, 3, relu=True, residual=shortcut)
 

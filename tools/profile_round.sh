@@ -6,11 +6,12 @@ TAG=${1:-r02}
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 mkdir -p $R/gpurun_out/prof_$TAG
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$TAG -o kt -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-workloads --no-hbm-classes --no-bf16x3-line > $R/gpurun_out/prof_$TAG/kt.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$TAG -o kt -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-workloads --no-hbm-classes --no-bf16x3-line --no-from-raw > $R/gpurun_out/prof_$TAG/kt.log 2>&1
 cp /tmp/kt_$TAG/kt_kernel_stats.csv $R/gpurun_out/prof_$TAG/${TAG}_kernel_stats.csv
+python $R/tools/stream_busy.py /tmp/kt_$TAG/kt_kernel_trace.csv --steps 3 > $R/gpurun_out/prof_$TAG/${TAG}_stream_busy_a2d2.txt 2>&1 || true
 grep -v "^[WEI]2026" $R/gpurun_out/prof_$TAG/kt.log | tail -1 > $R/gpurun_out/prof_$TAG/${TAG}_bench_under_rocprof.json
-timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pf_$TAG -o pf -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-workloads --no-hbm-classes --no-bf16x3-line --no-kernel-events > $R/gpurun_out/prof_$TAG/pf.log 2>&1
-timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pw_$TAG -o pw -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-workloads --no-hbm-classes --no-bf16x3-line --no-kernel-events > $R/gpurun_out/prof_$TAG/pw.log 2>&1
+timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pf_$TAG -o pf -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-workloads --no-hbm-classes --no-bf16x3-line --no-from-raw --no-kernel-events > $R/gpurun_out/prof_$TAG/pf.log 2>&1
+timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pw_$TAG -o pw -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-workloads --no-hbm-classes --no-bf16x3-line --no-from-raw --no-kernel-events > $R/gpurun_out/prof_$TAG/pw.log 2>&1
 python - <<PY
 import csv, collections, json
 out = {}
@@ -39,7 +40,7 @@ json.dump({"workload": "a2d2_kitti_128k", "hbm_bytes_per_launch": round((2 * f /
           open("$R/gpurun_out/prof_$TAG/${TAG}_conv_traffic.json", "w"), indent=1)
 PY
 # last, and allowed to fail: MFMA pipe utilisation of the conv kernels
-timeout -s KILL 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE --output-format csv -d /tmp/pm_$TAG -o pm -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-workloads --no-hbm-classes --no-bf16x3-line --no-kernel-events > $R/gpurun_out/prof_$TAG/pm.log 2>&1 || { echo "MFMA-busy pass failed"; exit 0; }
+timeout -s KILL 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE --output-format csv -d /tmp/pm_$TAG -o pm -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-workloads --no-hbm-classes --no-bf16x3-line --no-from-raw --no-kernel-events > $R/gpurun_out/prof_$TAG/pm.log 2>&1 || { echo "MFMA-busy pass failed"; exit 0; }
 python - <<PY
 import csv, collections, json
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
