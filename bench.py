@@ -366,6 +366,7 @@ def time_steps(step, batch, args, world, dev, backend, fwd_only=False, steps=Non
     if kernel_events:
         ops.conv_timer_begin(1 << 16)
         ops.conv_timer_arm(False)
+    wait0 = step.host_wait_s
     t0 = time.perf_counter()
     for i in range(steps):
         if kernel_events and i in sampled:
@@ -375,6 +376,7 @@ def time_steps(step, batch, args, world, dev, backend, fwd_only=False, steps=Non
         else:
             one_step()
     dt_host = time.perf_counter() - t0  # the host has issued every step (the GPU may still be working)
+    dt_wait = step.host_wait_s - wait0  # ... of which blocked on the run-ahead bound (2 steps in flight): GPU-bound time
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -394,7 +396,7 @@ def time_steps(step, batch, args, world, dev, backend, fwd_only=False, steps=Non
         pairs = [int(m.item()) for m in ops.CONV_PAIRS]
         ops.CONV_PAIRS = None
     step.close()
-    return dict(dt=dt, dt_host=dt_host, trace=trace, sampled=sampled, pairs=pairs, steps=steps)
+    return dict(dt=dt, dt_host=dt_host, dt_wait=dt_wait, trace=trace, sampled=sampled, pairs=pairs, steps=steps)
 
 
 def conv_roofline(r, args):
@@ -403,25 +405,42 @@ def conv_roofline(r, args):
     n_s = len(sampled)
     per_step = len(ms) // n_s
     assert len(pairs) == per_step and per_step * n_s == len(ms), (len(pairs), per_step, len(ms))
-    flops_step = sum(2.0 * m * int(cin) * int(cout) for m, (cin, cout, _k, _v) in zip(pairs, meta[:per_step]))
-    ms_total = float(ms.astype("float64").sum())
     if args.dump_conv:
         us = 1e3 * ms.reshape(n_s, per_step).mean(0)
         table = [dict(i=i, Cin=int(c[0]), Cout=int(c[1]), K=int(c[2]), Vout=int(c[3]), M=m, us=round(float(u), 1),
                       tflops=round(2.0 * m * int(c[0]) * int(c[1]) / float(u) / 1e6, 2))
                  for i, (m, c, u) in enumerate(zip(pairs, meta[:per_step], us))]
         json.dump(table, open(args.dump_conv, "w"))
-    launches = len(ms)
-    flops_total = flops_step * n_s
+    # The roofline family is the SPARSE convs (K = 8 or 27 offsets).  The one-call backbone pass also issues the network's
+    # dense layers (1x1x1 shortcut convs, point-branch Linears: K = 1 over an identity plan) through the same kernel; those
+    # are HBM-bound dense products (hipBLASLt GEMMs on the module path) and are reported beside the family, not inside it.
+    import numpy as np
+    ks = np.array([int(c[2]) for c in meta[:per_step]] * n_s)
+    sparse = ks > 1
+    fl = np.array([2.0 * m * int(c[0]) * int(c[1]) for m, c in zip(pairs, meta[:per_step])] * n_s)
+    msd = ms.astype("float64")
+    ms_total = float(msd[sparse].sum())
+    launches = int(sparse.sum())
+    flops_total = float(fl[sparse].sum())
     achieved = flops_total / (ms_total * 1e-3) / 1e12
-    return {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-            "kernel": "sparse-conv family (k_spconv_sj<SR,NTW,W> split-j fp32 MFMA; 4-channel stem: k_spconv_stem): every "
-                      "conv launch of the sampled steps of the timed region",
-            "launches": launches, "avg_launch_us": round(1e3 * ms_total / launches, 2),
-            "flops_per_launch": round(flops_total / launches),
-            "timed_steps": sampled,
-            "share_of_step": round(ms_total * 1e-3 / n_s / (r["dt"] / r["steps"]), 4)}
+    out = {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+           "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+           "kernel": "sparse-conv family (k_spconv_sj<SR,NTW,W> split-j fp32 MFMA; k_spconv_ls for the transposed 2^3 convs; "
+                     "4-channel stem: k_spconv_stem): every sparse-conv launch (K = 8 | 27) of the sampled steps of the "
+                     "timed region",
+           "launches": launches, "avg_launch_us": round(1e3 * ms_total / launches, 2),
+           "flops_per_launch": round(flops_total / launches),
+           "timed_steps": sampled,
+           "share_of_step": round(ms_total * 1e-3 / n_s / (r["dt"] / r["steps"]), 4)}
+    if (~sparse).any():
+        md = float(msd[~sparse].sum())
+        out["dense_layers_through_the_conv_kernel"] = {
+            "launches": int((~sparse).sum()), "avg_launch_us": round(1e3 * md / int((~sparse).sum()), 2),
+            "tflops": round(float(fl[~sparse].sum()) / (md * 1e-3) / 1e12, 3),
+            "share_of_step": round(md * 1e-3 / n_s / (r["dt"] / r["steps"]), 4),
+            "what": "1x1x1 shortcut convs and point-branch Linears (K = 1, identity plan, statistics in the epilogue): "
+                    "HBM-bound dense products, not part of the family above"}
+    return out
 
 
 def main():
@@ -564,7 +583,8 @@ def main():
                 others[oname] = {"value": ob["n_points"] * orr["steps"] / orr["dt"], "unit": "points/s",
                                  "ms_per_step": round(1e3 * orr["dt"] / orr["steps"], 3), "steps": orr["steps"],
                                  "points_per_step": ob["n_points"], "voxels": ob["n_voxels"],
-                                 "conv_tflops": oroof["achieved"], "conv_frac_mfma": oroof["frac"]}
+                                 "conv_tflops": oroof["achieved"], "conv_frac_mfma": oroof["frac"],
+                                 "host_busy_ms_per_step": round(1e3 * (orr["dt_host"] - orr["dt_wait"]) / orr["steps"], 3)}
                 if oname == "synthia_kitti_32k_b1" and not args.no_cpu_baseline:
                     # BASELINE configs[0] is THE CPU-reference configuration (one 32 768-point scan): the oracle's step on
                     # exactly that input, all threads and the reference's OMP_NUM_THREADS = 4
@@ -641,6 +661,9 @@ def main():
                                       + (", one flat RCCL all-reduce of the BatchNorm grads)" if world > 1 else ")"),
                        },
             "host_issue_ms_per_step": round(1e3 * r["dt_host"] / args.steps, 3),
+            # the main thread's own time: issue time minus the time step() sat blocked on the run-ahead bound (waiting for
+            # the GPU to finish the iteration before the previous one)
+            "host_busy_ms_per_step": round(1e3 * (r["dt_host"] - r["dt_wait"]) / args.steps, 3),
             "roofline": roof, "cpu_baseline": cpu,
         }
         if others is not None:

@@ -284,6 +284,10 @@ int lt_devoxelize_csr_bwd(const float* gout, const int32_t* perm, const int32_t*
  * see latte/models/hr_module.py:135-331 and :344-420; declared in the second half of this header */
 #include "latte_hip_st.h"
 
+/* ------------------------------------------------------------------ the backbone pass as one host call
+ * see latte/models/spvcnn.py:113-165; declared in the third part of this header */
+#include "latte_hip_net.h"
+
 #ifdef __cplusplus
 }
 #endif

@@ -101,7 +101,7 @@ int lt_quantile(const float* x, int64_t n, float q, void* ws, int64_t ws_bytes, 
  *          pointers NULL together: w = 1, the ety_weight=False / self_corr branch :379-380)
  *   row_loss[m] = w[m] * sum_c tr~ (log tr~ - log ac~), x~ = x == 0 ? 1e-8 : x   (the clamp on probabilities, :405-410)
  *   loss[0] = 1/B sum_b mean_{m in anchor b, keep[m]} row_loss[m]                (keep = tr_conf_mask :367-371; NULL: all)
- * Outputs kept for the backward: row_w [M], anchor_stats [B][2] = (sum, count) of the kept rows.  Two launches, fixed
+ * Outputs kept for the backward: row_w [M], anchor_stats [B][2] = (sum, count) of the kept rows.  Three launches, fixed
  * summation order, no sync.  C <= 64. */
 int lt_cr_loss_fwd(const float* ac, const float* tr, int64_t M, int32_t C, const float* ac_pc_ety, const int64_t* ac_p2v,
                    const float* tr_pc_ety, const int64_t* tr_p2v, const uint8_t* keep, const int32_t* anchor_start,

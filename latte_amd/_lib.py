@@ -102,6 +102,42 @@ SIGNATURES = {
     "lt_cr_loss_bwd": (ctypes.c_int, [P, P, I64, I32, P, P, P, P, I32, P, P, P]),
 }
 
+# include/latte_hip_net.h: the backbone pass as one call (host-side structs, see latte_amd/netprog.py)
+class NetOp(ctypes.Structure):
+    _fields_ = [("kind", I32), ("in0", I32), ("in1", I32), ("out", I32), ("layer", I32), ("map", I32), ("level", I32),
+                ("relu", I32)]
+
+
+class NetBuf(ctypes.Structure):
+    _fields_ = [("rows", I32), ("channels", I32)]
+
+
+class NetLayer(ctypes.Structure):
+    _fields_ = [("w_fwd", P), ("w_bwd", P), ("gamma", P), ("beta", P), ("eps", F32), ("cin", I32), ("cout", I32),
+                ("K", I32), ("dgamma_off", I64), ("dbeta_off", I64)]
+
+
+class NetProg(ctypes.Structure):
+    _fields_ = [("ops", ctypes.POINTER(NetOp)), ("n_ops", I32), ("bufs", ctypes.POINTER(NetBuf)), ("n_bufs", I32),
+                ("layers", ctypes.POINTER(NetLayer)), ("n_layers", I32), ("out_buf", I32)]
+
+
+class NetMaps(ctypes.Structure):
+    _fields_ = [("n_points", I64), ("n_vox", I64 * 5), ("plan_k3", P * 5), ("plan_down", P * 4), ("plan_up", P * 4),
+                ("plan_dense", P * 6), ("p2v_perm", P * 5), ("p2v_off", P * 5), ("p2v_idx", P * 5), ("p2v_counts", P * 5),
+                ("v2p_idx", P * 5), ("v2p_w", P * 5), ("v2p_perm", P * 5), ("v2p_off", P * 5)]
+
+
+_SIGS = {
+    "lt_kmap_plan_identity": (ctypes.c_int, [I64, P, I64, P]),
+    "lt_net_arena_floats": (I64, [ctypes.POINTER(NetProg), ctypes.POINTER(NetMaps), P, I32]),
+    "lt_net_forward": (ctypes.c_int, [ctypes.POINTER(NetProg), ctypes.POINTER(NetMaps), P, P, I64, I32, P, P]),
+    "lt_net_grad_arena_floats": (I64, [ctypes.POINTER(NetProg), ctypes.POINTER(NetMaps), P]),
+    "lt_net_backward": (ctypes.c_int, [ctypes.POINTER(NetProg), ctypes.POINTER(NetMaps), P, P, I64, P, P, P, I64, P]),
+}
+SIGNATURES.update(_SIGS)
+
+
 _lib = None
 
 

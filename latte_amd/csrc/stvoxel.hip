@@ -701,7 +701,7 @@ extern "C" int lt_quantile(const float* x, int64_t n, float q, void* ws, int64_t
 // CR_Block (latte/models/hr_module.py:344-420): entropy-weighted KL between matched anchor / hist ST-voxel distributions,
 // mean over the kept rows of every anchor, mean over the anchors.  The reference loops over the anchors in Python with ~12
 // elementwise launches each; here all anchors are rows of one matrix (rows sorted by anchor: anchor_start[B+1]) and the
-// loss is two kernels forward (rows, then a fixed-order per-anchor reduction) and one backward.
+// loss is three kernels forward (rows, a fixed-order reduction per anchor, the mean over the anchors) and one backward.
 //   w[m]    = exp(-t_e) / (exp(-t_e) + exp(-a_e)),  a_e = ac_pc_ety[ac_p2v[m]], t_e = tr_pc_ety[tr_p2v[m]]   (:373-377)
 //   row[m]  = w[m] * sum_c tr~ * (log tr~ - log ac~),  x~ = (x == 0 ? 1e-8 : x): the clamp acts on PROBABILITIES (Q6, :405-406)
 //   loss    = 1/B * sum_b  sum_{m in b, keep[m]} row[m] / #{m in b : keep[m]}                                 (:407-420)
@@ -733,37 +733,40 @@ __global__ void k_cr_rows(const float* __restrict__ ac, const float* __restrict_
   }
 }
 
-// ONE workgroup: per anchor a fixed-order block reduction of (sum of kept rows, number of kept rows), then the mean over
-// the anchors.  stats[b] = (num_b, den_b) is kept for the backward.  M is a few 1e4..1e5 rows: ~100 rows per thread.
+// One workgroup per anchor: a fixed-order block reduction of (sum of kept rows, number of kept rows); stats[b] = (num_b,
+// den_b) is kept for the backward.  Then one wave takes the mean over the anchors in anchor order.  (A single workgroup
+// walking all anchors cost 75 us a launch on the 64-anchor workload; this is B-way parallel and ~5 us.)
 __global__ __launch_bounds__(1024) void k_cr_reduce(const float* __restrict__ row_loss, const uint8_t* __restrict__ keep,
-                                                    const int* __restrict__ anchor_start, int B, float* __restrict__ stats,
-                                                    float* __restrict__ loss) {
+                                                    const int* __restrict__ anchor_start, float* __restrict__ stats) {
   __shared__ float s_num[1024], s_den[1024];
-  const int t = threadIdx.x;
-  float total = 0.f;
-  for (int b = 0; b < B; ++b) {
-    const int r0 = anchor_start[b], r1 = anchor_start[b + 1];
-    float num = 0.f, den = 0.f;
-    for (int m = r0 + t; m < r1; m += 1024) {
-      const float k = keep ? (keep[m] ? 1.f : 0.f) : 1.f;
-      num += k * row_loss[m];
-      den += k;
-    }
-    s_num[t] = num;
-    s_den[t] = den;
-    __syncthreads();
-    for (int s = 512; s > 0; s >>= 1) {
-      if (t < s) { s_num[t] += s_num[t + s]; s_den[t] += s_den[t + s]; }
-      __syncthreads();
-    }
-    if (t == 0) {
-      stats[2 * b] = s_num[0];
-      stats[2 * b + 1] = s_den[0];
-      total += s_num[0] / s_den[0];        // an anchor without a kept row: 0/0 = NaN, like the reference's mean of nothing
-    }
+  const int t = threadIdx.x, b = blockIdx.x;
+  const int r0 = anchor_start[b], r1 = anchor_start[b + 1];
+  float num = 0.f, den = 0.f;
+  for (int m = r0 + t; m < r1; m += 1024) {
+    const float k = keep ? (keep[m] ? 1.f : 0.f) : 1.f;
+    num += k * row_loss[m];
+    den += k;
+  }
+  s_num[t] = num;
+  s_den[t] = den;
+  __syncthreads();
+  for (int s = 512; s > 0; s >>= 1) {
+    if (t < s) { s_num[t] += s_num[t + s]; s_den[t] += s_den[t + s]; }
     __syncthreads();
   }
-  if (t == 0) loss[0] = total / (float)B;
+  if (t == 0) {
+    stats[2 * b] = s_num[0];
+    stats[2 * b + 1] = s_den[0];
+  }
+}
+
+__global__ void k_cr_final(const float* __restrict__ stats, int B, float* __restrict__ loss) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    float total = 0.f;
+    for (int b = 0; b < B; ++b)
+      total += stats[2 * b] / stats[2 * b + 1];   // an anchor without a kept row: 0/0 = NaN, like the reference's mean of nothing
+    loss[0] = total / (float)B;
+  }
 }
 
 __global__ void k_cr_bwd(const float* __restrict__ ac, const float* __restrict__ tr, int64_t M, int C,
@@ -810,7 +813,9 @@ extern "C" int lt_cr_loss_fwd(const float* ac, const float* tr, int64_t M, int32
                        tr_p2v, row_w, row_loss);
     LT_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(k_cr_reduce, dim3(1), dim3(1024), 0, stream, row_loss, keep, anchor_start, B, anchor_stats, loss);
+  hipLaunchKernelGGL(k_cr_reduce, dim3(B), dim3(1024), 0, stream, row_loss, keep, anchor_start, anchor_stats);
+  LT_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_cr_final, dim3(1), dim3(64), 0, stream, anchor_stats, B, loss);
   LT_LAUNCH_CHECK();
   return LT_OK;
 }

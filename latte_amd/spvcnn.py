@@ -227,9 +227,35 @@ class SPVCNN(nn.Module):
             p2v_index(levels[s], z)
             if backward:
                 v2p_csr(levels[s], z)
+        if x.feats.is_cuda and min(int(levels[s].C.shape[0]) for s in levels) >= 2:
+            # what the one-call pass (netprog / lt_net_forward) takes: every structure above as one struct of pointers
+            from . import netprog
+            cache["levels"] = levels
+            cache["net_maps"] = netprog.build_maps(cache, z, levels)
         cache["prepared"] = True
 
+    def _program(self):
+        prog = self.__dict__.get("_lt_prog")
+        if prog is None:
+            from . import netprog
+            prog = self.__dict__["_lt_prog"] = netprog.NetProgram(self)
+        return prog
+
     def forward(self, x: SparseTensor) -> torch.Tensor:
+        if x.feats.is_cuda:
+            # the shipped TTA configuration (frozen kernels, batch statistics, no dropout): the whole pass is one call into
+            # the library (netprog.py / lt_net_forward); everything else walks the module tree below
+            prog = self._program()
+            if prog.eligible(x.feats):
+                self.prepare(x, backward=True)
+                cache, _ = self._batch_cache(x)
+                maps = cache.get("net_maps")
+                if maps is not None and maps.struct.v2p_perm[0]:
+                    from . import netprog
+                    return netprog.run(prog, x.feats, maps, cache["levels"])
+        return self._forward_modules(x)
+
+    def _forward_modules(self, x: SparseTensor) -> torch.Tensor:
         cache, z = self._batch_cache(x)
         x0 = self._stem(initial_voxelize(z, self.pres, self.vres, cache))
         z0 = voxel_to_point(x0, z, nearest=False)

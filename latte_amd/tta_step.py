@@ -11,6 +11,7 @@ Host-side restatement of latte/tta/tools/latte.py:133-323 with the 2-D SegFormer
 Model configuration helpers mirror latte/common/utils/ema_util.py:6-41,74-118."""
 from __future__ import annotations
 
+import time
 from copy import deepcopy
 from typing import Dict, List
 
@@ -413,6 +414,7 @@ class LatteStep:
             if sys.getswitchinterval() > want:
                 sys.setswitchinterval(want)
         self._inflight: List = []   # end-of-step events of the iterations the GPU may still be working on
+        self.host_wait_s = 0.0      # seconds step() spent blocked on the run-ahead bound (the host was ahead of the GPU)
         if self.hr_side_stream and self.params[0].is_cuda:
             ensure_side_stream(self.params[0].device)   # created now, not inside the first step (deterministic creation order)
 
@@ -710,8 +712,11 @@ class LatteStep:
         # the GPU (a host wait on an event recorded at the end of that step; free while the step is GPU-bound, the host
         # is < 1 step ahead then).  It keeps the number of outstanding packets / completion signals / allocator blocks of
         # every stream bounded by two iterations' worth, whatever the caller's loop does.
-        while len(self._inflight) >= MAX_STEPS_IN_FLIGHT:
-            self._inflight.pop(0).synchronize()
+        if len(self._inflight) >= MAX_STEPS_IN_FLIGHT:
+            t0 = time.perf_counter()
+            while len(self._inflight) >= MAX_STEPS_IN_FLIGHT:
+                self._inflight.pop(0).synchronize()
+            self.host_wait_s += time.perf_counter() - t0   # blocked on the GPU, not working (bench: host_busy_ms_per_step)
         # one TTA iteration = one new batch: index structures are built once per iteration (ahead of it by prefetch(), or
         # by the teacher forward) and shared with the student forward, never carried over from an earlier iteration
         pre = self._take_prefetched(batch)

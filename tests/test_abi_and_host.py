@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _declared():
     names = set()
-    for h in ("latte_hip.h", "latte_hip_st.h"):
+    for h in ("latte_hip.h", "latte_hip_st.h", "latte_hip_net.h"):
         txt = open(os.path.join(ROOT, "include", h)).read()
         txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
         names |= set(re.findall(r"\b(lt_[a-z0-9_]+)\s*\(", txt))
