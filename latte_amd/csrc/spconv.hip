@@ -879,271 +879,14 @@ static int launch_rf(const PlanArgs& a, int sr, hipStream_t stream) {
 
 template <int SR, int NTW, int W>
 __global__ __launch_bounds__(64 * W) void k_spconv_sj(PlanArgs a) {
-  constexpr int PARTS = SR >= 4 ? 1 : 4 / SR;  // workgroups per plan tile (SR < 4: a workgroup owns SR of its 4 strips)
-  constexpr int TMW = 16 * SR;                 // rows per workgroup (SR in {1,2,4}: at most one plan tile)
-  __shared__ int s_nbr[LT_KMAX * TMW];  // [nact][TMW] neighbour rows of the active offsets
-  __shared__ int s_rows[TMW];
-  __shared__ int s_klist[LT_KMAX];
-  __shared__ unsigned int s_act[LT_KMAX];  // per active offset: bit h = strip h has a neighbour
-  __shared__ int s_nact;
-  __shared__ f32x4 s_red[W * NTW * 64];  // [W][NTW][64] partial accumulators of one strip
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r = lane & 15, q = lane >> 4;
-  long long st0 = 0, st1 = 0, st2 = 0, rt0 = 0;
-  if (a.dbg & 4) { st0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
-  // XCD-aware mapping of the 1-D grid (see k_spconv_rf)
-  const unsigned gy = a.Cout / (16 * NTW);
-  unsigned bx, by;
-  if (a.swz) {
-    const unsigned L = blockIdx.x, i = L >> 3;
-    bx = (i / gy) * 8 + (L & 7);
-    by = i % gy;
-  } else {
-    bx = blockIdx.x % a.gx;
-    by = blockIdx.x / a.gx;
-  }
-  if (bx >= (unsigned)a.gx || by >= gy) return;  // padding of the 1-D grid
-  const int64_t tile0 = (int64_t)a.torder[bx / PARTS];  // heaviest tile first
-  const int s0 = PARTS == 1 ? 0 : (int)(bx % PARTS) * SR;  // first strip inside the plan tile
-  const int J = a.Cin / 16, NTt = a.Cout / 16;
-  const int JW = J / W;  // slabs per offset and wave (host: J % W == 0)
-  const int nt0 = by * NTW;
-
-  if (wave == 0) {
-    unsigned int act = 0u;
-    unsigned long long m = 0ull;
-    if (lane < a.K) m = a.tmask[tile0 * a.K + lane];
-#pragma unroll
-    for (int st = 0; st < SR; ++st)
-      if ((m >> (16 * (s0 + st))) & 0xFFFFull) act |= 1u << st;
-    const unsigned long long bal = __ballot(act != 0u);
-    if (act != 0u) {
-      const int pos = __popcll(bal & ((1ull << lane) - 1ull));
-      s_klist[pos] = lane;
-      s_act[pos] = act;
-    }
-    if (lane == 0) s_nact = __popcll(bal);
-  }
-  for (int i = tid; i < TMW; i += 64 * W) {
-    const int64_t slot = tile0 * LT_TM + 16 * s0 + i;
-    s_rows[i] = slot < a.Vout ? a.order[slot] : -1;
-  }
-  __syncthreads();
-  const int nact = s_nact;
-  for (int e = tid; e < nact * TMW; e += 64 * W) {
-    const int ki = e / TMW, i = e - ki * TMW;
-    int v = a.tnbr[(tile0 * a.K + s_klist[ki]) * LT_TM + 16 * s0 + i];
-    if (v >= a.Vin) v = -1;  // defensive: never gather out of bounds
-    s_nbr[e] = v;
-  }
-  __syncthreads();
-  // per-offset table in registers: lane ki holds entry ki
-  const int kl_v = lane < nact ? s_klist[lane] : 0;
-  const unsigned int act_v = lane < nact ? s_act[lane] : 0u;
-
-  f32x4 acc[SR][NTW];
-#pragma unroll
-  for (int h = 0; h < SR; ++h)
-#pragma unroll
-    for (int n = 0; n < NTW; ++n) acc[h][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  // Operands are read with raw buffer loads: a 32-bit per-lane offset that changes once per offset k, a scalar offset that
-  // moves from slab to slab, no vector address arithmetic in the loop.  A missing neighbour gets a per-lane offset past
-  // the end of the buffer: the hardware range check returns zeros for it and no memory is touched.
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0,
-                                                                        (int)((int64_t)a.Vin * a.Cin * 4), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.packed), 0,
-                                                                        (int)((int64_t)a.K * a.Cin * a.Cout * 4), 0x00020000);
-  const int lane_a = (4 * q + 16 * wave) * 4;             // bytes into a gathered row: this wave's first channel group
-  const int lane_b = lane * 16;                           // bytes into a packed 1-KiB fragment
-  const int row_bytes = a.Cin * 4;
-  const int wstep = W * NTt * 1024;                       // bytes from channel group j to j + W in the packed image
-  const int wkstep = J * NTt * 1024;                      // ... from offset k to k + 1
-  const int wbase = (wave * NTt + nt0) * 1024;
-  if (a.dbg & 4) st1 = __builtin_amdgcn_s_memtime();
-
-  const int Uw = nact * JW;  // slabs of this wave
-  if (Uw > 0) {
-    // state of the offset being issued
-    int voff[SR];            // per-lane byte offset of the gathered row (past the end: no neighbour)
-    int soff_b;              // scalar byte offset of the packed fragment of (k, j)
-    int soff_a = 0;          // scalar byte offset inside the row: 64 * W * jj
-    unsigned int act_cur;
-    int srcn[SR];  // neighbour rows of the next offset (read from LDS one offset ahead)
-    int ki = 0, jj = 0;
-    auto install = [&]() {  // ki < nact: make offset ki current; otherwise: past the end (no work, loads return zeros)
-      if (ki < nact) {
-        const int k = __builtin_amdgcn_readlane(kl_v, ki);
-        act_cur = (unsigned int)__builtin_amdgcn_readlane((int)act_v, ki);
-        soff_b = wbase + ((a.dbg & 1) ? 0 : k) * wkstep;  // dbg & 1 / & 2: diagnostics with cache-resident weights / rows
-#pragma unroll
-        for (int h = 0; h < SR; ++h)
-          voff[h] = srcn[h] >= 0 ? ((a.dbg & 2) ? (srcn[h] & 1023) : srcn[h]) * row_bytes + lane_a : 0x7FFFF000;
-        const int kn = ki + 1 < nact ? ki + 1 : ki;
-#pragma unroll
-        for (int h = 0; h < SR; ++h) srcn[h] = s_nbr[kn * TMW + 16 * h + r];
-      } else {
-        act_cur = 0u;
-#pragma unroll
-        for (int h = 0; h < SR; ++h) voff[h] = 0x7FFFF000;
-      }
-    };
-#pragma unroll
-    for (int h = 0; h < SR; ++h) srcn[h] = s_nbr[16 * h + r];
-    install();
-    // addresses of the slab to load next, captured before the state moves on
-    int nvoff[SR], nsoff_a, nsoff_b;
-    unsigned int nact_bits;
-    auto capture_and_advance = [&]() {
-      nact_bits = act_cur;
-      nsoff_a = soff_a;
-      nsoff_b = soff_b;
-#pragma unroll
-      for (int h = 0; h < SR; ++h) nvoff[h] = voff[h];
-      if (++jj == JW) {  // wave-uniform: next offset
-        jj = 0;
-        soff_a = 0;
-        ++ki;
-        install();
-      } else {
-        soff_a += 64 * W;
-        soff_b += wstep;
-      }
-    };
-    auto load_one = [&](int ld, f32x4 (&av2)[SR], f32x4 (&bv2)[NTW]) {
-      // order: strip 0's rows, the weights, the other strips' rows -- what the next slab multiplies first comes first
-      if (ld == 0) {
-        av2[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, nvoff[0], nsoff_a, 0));
-      } else if (ld <= NTW) {
-        bv2[ld - 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, lane_b + (ld - 1) * 1024, nsoff_b, 0));
-      } else if (ld < NTW + SR) {
-        av2[ld - NTW] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, nvoff[ld - NTW], nsoff_a, 0));
-      }
-    };
-    // The operand loads of the next slab are spread over the MFMA groups of the current one (one load after every NTW
-    // MFMAs) instead of being issued as a burst: a vector-memory instruction costs ~60+ cycles of issue, a burst of
-    // SR+NTW of them from every wave backs the address path up and the MFMA pipe idles meanwhile (282 -> 230 us at
-    // stride 8, C=256).
-    auto compute_and_load = [&](unsigned int act, const f32x4 (&av)[SR], const f32x4 (&bv)[NTW], f32x4 (&av2)[SR],
-                                f32x4 (&bv2)[NTW]) {
-      constexpr int NL = NTW + SR;               // loads of a slab
-      constexpr int PER = (NL + SR - 1) / SR;    // ... issued beside one strip's MFMAs
-#pragma unroll
-      for (int h = 0; h < SR; ++h) {
-        const bool on = (act >> h) & 1u;  // wave-uniform: the strip has a neighbour at this offset
-        if (!on) {
-#pragma unroll
-          for (int e = 0; e < PER; ++e) load_one(h * PER + e, av2, bv2);
-        }
-        if (on) {
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-#pragma unroll
-            for (int n = 0; n < NTW; ++n)
-              acc[h][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[h][t], bv[n][t], acc[h][n], 0, 0, 0);
-            if (t < PER) load_one(h * PER + t, av2, bv2);
-          }
-#pragma unroll
-          for (int e = 4; e < PER; ++e) load_one(h * PER + e, av2, bv2);
-          // keep the loads where they were written: one after every NTW MFMAs
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            __builtin_amdgcn_sched_group_barrier(0x008, NTW, 0);
-            if (t < PER && h * PER + t < NL) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-          }
-        }
-      }
-    };
-    f32x4 avA[SR], avB[SR], bA[NTW], bB[NTW];
-    unsigned int actA = 0u, actB = 0u;
-    // first slab: plain burst
-    capture_and_advance();
-    actA = nact_bits;
-#pragma unroll
-    for (int e = 0; e < NTW + SR; ++e) load_one(e, avA, bA);
-    for (int u = 0; u < Uw; u += 2) {
-      capture_and_advance();
-      actB = nact_bits;
-      compute_and_load(actA, avA, bA, avB, bB);
-      capture_and_advance();
-      actA = nact_bits;
-      compute_and_load(actB, avB, bB, avA, bA);
-    }
-  }
-  if (a.dbg & 4) st2 = __builtin_amdgcn_s_memtime();
-
-  // strip h is finished by wave h % W: partial accumulators of the others through LDS, added in wave order; the
-  // finishing wave stores the rows and keeps their column sums
-  float s1[NTW], s2[NTW];
-#pragma unroll
-  for (int n = 0; n < NTW; ++n) s1[n] = s2[n] = 0.f;
-#pragma unroll
-  for (int h = 0; h < SR; ++h) {
-    const int owner = h % W;
-    f32x4* red = s_red;
-    if (h > 0) __syncthreads();  // the previous strip's partials have been read
-    if (wave != owner) {
-#pragma unroll
-      for (int n = 0; n < NTW; ++n) red[(wave * NTW + n) * 64 + lane] = acc[h][n];
-    }
-    __syncthreads();
-    if (wave == owner) {
-#pragma unroll
-      for (int n = 0; n < NTW; ++n) {
-        f32x4 sum = owner == 0 ? acc[h][n] : red[n * 64 + lane];
-#pragma unroll
-        for (int w = 1; w < W; ++w) {
-          const f32x4 v = w == owner ? acc[h][n] : red[(w * NTW + n) * 64 + lane];
-          sum[0] += v[0]; sum[1] += v[1]; sum[2] += v[2]; sum[3] += v[3];
-        }
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          const int row = s_rows[16 * h + 4 * q + reg];
-          if (row >= 0) a.out[(int64_t)row * a.Cout + 16 * (nt0 + n) + r] = sum[reg];
-          s1[n] += sum[reg];
-          s2[n] += sum[reg] * sum[reg];
-        }
-      }
-    }
-  }
-  if (a.partial) {
-    // column sums of the workgroup's rows: per wave over its strips, then over the waves in wave order through LDS
-    float* redf = reinterpret_cast<float*>(s_red);  // [W][NTW][2][16]
-    __syncthreads();                                // the last strip's partial accumulators have been read
-#pragma unroll
-    for (int n = 0; n < NTW; ++n) {
-      float t1 = s1[n], t2 = s2[n];
-      t1 += __shfl_xor(t1, 16, 64); t2 += __shfl_xor(t2, 16, 64);
-      t1 += __shfl_xor(t1, 32, 64); t2 += __shfl_xor(t2, 32, 64);
-      if (q == 0) {
-        redf[((wave * NTW + n) * 2 + 0) * 16 + r] = t1;
-        redf[((wave * NTW + n) * 2 + 1) * 16 + r] = t2;
-      }
-    }
-    __syncthreads();
-    if (wave == 0 && lane < 32) {
-      const int which = lane >> 4;
-#pragma unroll
-      for (int n = 0; n < NTW; ++n) {
-        float t = 0.f;
-#pragma unroll
-        for (int w = 0; w < W; ++w) t += redf[((w * NTW + n) * 2 + which) * 16 + r];
-        a.partial[((int64_t)bx * 2 + which) * a.Cout + 16 * (nt0 + n) + r] = t;
-      }
-    }
-  }
-  if ((a.dbg & 4) && a.stamps && lane == 0) {
-    unsigned hwid, xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    long long* o = a.stamps + ((long long)blockIdx.x * W + wave) * 8;
-    o[0] = st0; o[1] = st1; o[2] = st2; o[3] = __builtin_amdgcn_s_memtime();
-    o[4] = rt0; o[5] = __builtin_amdgcn_s_memrealtime();
-    o[6] = (long long)(nact * J) | ((long long)nact << 32);
-    o[7] = (long long)hwid | ((long long)xcc << 32);
-  }
+#include "spconv_sj_body.inc"
+}
+// The same code under its own name for the K = 1 launches (the network's dense layers over lt_kmap_plan_identity: 1x1x1
+// shortcut convs, point-branch Linears).  A kernel trace then tells the HBM-bound dense products from the sparse convs
+// (bench.py's roofline family and the rocprofv3 summaries under profiles/ count k_spconv_* only).
+template <int SR, int NTW, int W>
+__global__ __launch_bounds__(64 * W) void k_dense_sj(PlanArgs a) {
+#include "spconv_sj_body.inc"
 }
 
 template <int SR, int NTW, int W>
@@ -1154,7 +897,8 @@ static void launch_sj_one(const PlanArgs& a, hipStream_t stream) {
   const unsigned gy = (unsigned)(a.Cout / (16 * NTW));
   const unsigned total = ((gx + 7) / 8) * 8 * gy;
   if (b.stamps && g_conv_stamps_cap < (long long)total * W * 8) b.stamps = nullptr;
-  LT_CONV_LAUNCH((k_spconv_sj<SR, NTW, W>), dim3(total), dim3(64 * W), stream, b);
+  if (b.K == 1) LT_CONV_LAUNCH((k_dense_sj<SR, NTW, W>), dim3(total), dim3(64 * W), stream, b);
+  else LT_CONV_LAUNCH((k_spconv_sj<SR, NTW, W>), dim3(total), dim3(64 * W), stream, b);
 }
 
 // split-j launch: sr in {1,2,4}, ntw in {2,3,4}, w in {2,3,4,6,8}; needs (Cin/16) % w == 0

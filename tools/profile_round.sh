@@ -10,10 +10,8 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/k
 cp /tmp/kt_$TAG/kt_kernel_stats.csv $R/gpurun_out/prof_$TAG/${TAG}_kernel_stats.csv
 python $R/tools/stream_busy.py /tmp/kt_$TAG/kt_kernel_trace.csv --steps 3 > $R/gpurun_out/prof_$TAG/${TAG}_stream_busy_a2d2.txt 2>&1 || true
 grep -v "^[WEI]2026" $R/gpurun_out/prof_$TAG/kt.log | tail -1 > $R/gpurun_out/prof_$TAG/${TAG}_bench_under_rocprof.json
-# The counter passes run the module-by-module path (LATTE_NET_EXEC=0): the sparse-conv launches are the same kernels with
-# the same arguments as in the one-call pass, but there the network's dense layers (K = 1) ALSO go through k_spconv_sj and
-# a kernel name cannot tell them apart -- the roofline family (and its traffic / MFMA-busy figures) is the sparse convs.
-export LATTE_NET_EXEC=0
+# the conv family = kernels named k_spconv_*; the network's dense layers (K = 1 over an identity plan) run the same code
+# under the name k_dense_sj and are not counted
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pf_$TAG -o pf -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-workloads --no-hbm-classes --no-bf16x3-line --no-from-raw --no-kernel-events > $R/gpurun_out/prof_$TAG/pf.log 2>&1
 timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pw_$TAG -o pw -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-workloads --no-hbm-classes --no-bf16x3-line --no-from-raw --no-kernel-events > $R/gpurun_out/prof_$TAG/pw.log 2>&1
 python - <<PY
@@ -40,7 +38,7 @@ json.dump({"workload": "a2d2_kitti_128k", "hbm_bytes_per_launch": round((2 * f /
                          "WRITE_SIZE as reported; KB -> bytes x1024",
            "dispatches": n,
            "source": "profiles/$TAG" + "_pmc_hbm.json (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, "
-                     "bench.py --steps 2 --warmup 1, LATTE_NET_EXEC=0 so that only the sparse convs run on the conv kernels)"},
+                     "bench.py --steps 2 --warmup 1)"},
           open("$R/gpurun_out/prof_$TAG/${TAG}_conv_traffic.json", "w"), indent=1)
 PY
 # last, and allowed to fail: MFMA pipe utilisation of the conv kernels
