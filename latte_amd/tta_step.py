@@ -527,23 +527,42 @@ class LatteStep:
 
         def body():
             try:
+                if _KEEP_CACHE and factory is None and getattr(self, "_diag_kept", None) is not None \
+                        and self._diag_kept[0] is batch \
+                        and __import__("os").environ.get("LATTE_DIAG_KEEP_INDEX_CACHE") not in ("prepare", "geometry"):
+                    # diagnostics only (LATTE_DIAG_KEEP_INDEX_CACHE, not legitimate): hand the structures of the last
+                    # prefetch of this very batch over again -- the step then runs WITHOUT the side stream's work, which
+                    # bounds what that work costs the main stream
+                    box.update(self._diag_kept[1])
+                    return
                 with torch.cuda.device(dev), torch.no_grad(), torch.cuda.stream(side):
                     if factory is not None:
                         b = factory()            # H2D + input voxelization + collate, on the side stream
                     else:
                         b = batch
                         side.wait_event(ready)
+                    kept = getattr(self, "_diag_kept", None) if (_KEEP_CACHE and factory is None) else None
+                    part = __import__("os").environ.get("LATTE_DIAG_KEEP_INDEX_CACHE", "")
+                    if kept is not None and kept[0] is not batch:
+                        kept = None
                     tab = self._batch_tables(b)
                     x = b["lidar"]
                     view = SparseTensor(x.F, x.C, x.s)   # same tensors, own cache slot
+                    if kept is not None and part == "prepare":      # diagnostics: only the backbone's structures are reused
+                        view._lt_cache = kept[1]["cache"]
                     self.model.net_3d.prepare(view)
-                    a2, h2, a3, h3 = self._hr_inputs(b, tab)
-                    box["geo23"] = self.hr.geometry(a2, "2D", h3, "3D")
-                    box["geo32"] = self.hr.geometry(a3, "3D", h2, "2D")
+                    if kept is not None and part == "geometry":     # diagnostics: only the HR geometry is reused
+                        box["geo23"], box["geo32"] = kept[1]["geo23"], kept[1]["geo32"]
+                    else:
+                        a2, h2, a3, h3 = self._hr_inputs(b, tab)
+                        box["geo23"] = self.hr.geometry(a2, "2D", h3, "3D")
+                        box["geo32"] = self.hr.geometry(a3, "3D", h2, "2D")
                     box["batch"], box["tab"], box["cache"] = b, tab, view._lt_cache
                     # what the consumer waits for: this batch's structures, not whatever the side stream does next
                     box["done"] = torch.cuda.Event()
                     box["done"].record(side)
+                    if _KEEP_CACHE and factory is None:
+                        self._diag_kept = (batch, dict(box))
             except BaseException as e:  # re-raised by the step that joins
                 box["error"] = e
 
