@@ -206,6 +206,14 @@ int lt_bn_finalize_sums(void* stats_ws, int64_t V, int32_t C, float* mean, float
 int lt_bn_apply(const float* x, const float* mean, const float* var, const float* gamma, const float* beta,
                 float eps, const float* residual, int32_t relu, float* y, int64_t V, int32_t C,
                 lt_stream_t stream);
+/* The point branch with the devoxelized addend formed on the fly (latte/models/spvcnn.py:141-142,152-153,163-164:
+ * z.F = voxel_to_point(x, z).F + point_transforms(z.F)):
+ *   y[p,:] = relu(bn(x[p,:])) + sum_{k<8} w[p,k] * vox[idx[p,k],:]       (idx < 0: corner skipped)
+ * = lt_devoxelize_fwd followed by lt_bn_apply(relu = 3), bit for bit, without writing and re-reading the [N,C]
+ * devoxelized tensor.  idx [N,8] int32, w [N,8] (lt_calc_ti_weights, transposed), vox [V,C]. */
+int lt_bn_apply_devox(const float* x, const float* mean, const float* var, const float* gamma, const float* beta, float eps,
+                      const float* vox, const int32_t* idx, const float* w, float* y, int64_t N, int32_t C, int64_t V,
+                      lt_stream_t stream);
 /* g = dy * mask;  sum_g[c] = sum g;  sum_gx[c] = sum g*xhat.  relu: 0 = no ReLU (mask = 1); 1 = mask = (y > 0), y read;
  * 2 = the forward added no residual: mask = (gamma*xhat + beta > 0) rebuilt from x with the forward's own expression
  * (bit-identical to y > 0), y is not read (may be NULL), gamma / beta are needed (NULL allowed for relu 0 / 1). */

@@ -68,6 +68,7 @@ SIGNATURES = {
     "lt_bn_stats": (ctypes.c_int, [P, I64, I32, P, I64, P, P, P]),
     "lt_bn_stats_static": (ctypes.c_int, [P, I64, I32, P, P, P]),
     "lt_bn_apply": (ctypes.c_int, [P, P, P, P, P, F32, P, I32, P, I64, I32, P]),
+    "lt_bn_apply_devox": (ctypes.c_int, [P, P, P, P, P, F32, P, P, P, P, I64, I32, I64, P]),
     "lt_bn_bwd_reduce": (ctypes.c_int, [P, P, P, P, P, P, P, F32, I32, I64, I32, P, I64, P, P, P]),
     "lt_bn_bwd_apply": (ctypes.c_int, [P, P, P, P, P, P, P, F32, I32, P, P, P, P, I64, I32, P]),
     "lt_head_gather_fwd": (ctypes.c_int, [P, P, P, P, I64, I64, I32, I32, I32, P, P, P]),

@@ -204,6 +204,48 @@ int64_t buf_floats(const lt_net_prog_t* p, const lt_net_maps_t* m, int b) {
   return al64(rows_of(m, p->bufs[b].rows) * (int64_t)p->bufs[b].channels);
 }
 
+// how many ops read each buffer
+std::vector<int> reader_count(const lt_net_prog_t* p) {
+  std::vector<int> n(p->n_bufs, 0);
+  for (int i = 0; i < p->n_ops; ++i) {
+    ++n[p->ops[i].in0];
+    if (p->ops[i].in1 >= 0 && p->ops[i].in1 != p->ops[i].in0) ++n[p->ops[i].in1];
+  }
+  return n;
+}
+
+// Devoxelize ops folded into their reader: out = relu(bn(conv(in0))) + devox(v) with the devoxelized tensor read by this
+// op alone is issued as conv + statistics, finalize, lt_bn_apply_devox -- the [points, C] addend is formed inside the apply
+// kernel from the voxel rows and never exists in memory (2 x 4NC bytes per point branch and pass: ~1 ms of the a2d2 step).
+// fused[j] = index of the DEVOX op folded into CONV_BN op j (-1: none); skip[d] = 1 for those DEVOX ops.  Its backward is
+// unchanged (the addend's gradient is the output's, see addend_takes_dy).  LT_NET_FUSE_DEVOX=0 switches it off (A/B).
+struct DevoxFusion {
+  std::vector<int> fused;
+  std::vector<char> skip;
+};
+DevoxFusion devox_fusion(const lt_net_prog_t* p) {
+  static const bool on = [] {
+    const char* e = getenv("LT_NET_FUSE_DEVOX");
+    return !(e && e[0] == '0');
+  }();
+  DevoxFusion f;
+  f.fused.assign(p->n_ops, -1);
+  f.skip.assign(p->n_ops, 0);
+  if (!on) return f;
+  const std::vector<int> readers = reader_count(p);
+  std::vector<int> producer(p->n_bufs, -1);
+  for (int i = 0; i < p->n_ops; ++i) producer[p->ops[i].out] = i;
+  for (int j = 0; j < p->n_ops; ++j) {
+    const lt_net_op_t& op = p->ops[j];
+    if (op.kind != LT_NET_CONV_BN || op.relu != 3 || op.in1 < 0 || op.in1 == op.in0 || op.map == LT_NET_MAP_STEM) continue;
+    const int d = producer[op.in1];
+    if (d < 0 || d >= j || p->ops[d].kind != LT_NET_DEVOX || readers[op.in1] != 1 || op.in1 == p->out_buf) continue;
+    f.fused[j] = d;
+    f.skip[d] = 1;
+  }
+  return f;
+}
+
 int fwd_layout(const lt_net_prog_t* p, const lt_net_maps_t* m, const float* const* ext, bool keep, FwdLayout* L) {
   const int nb = p->n_bufs, no = p->n_ops;
   L->off.assign(nb, -1);
@@ -215,6 +257,14 @@ int fwd_layout(const lt_net_prog_t* p, const lt_net_maps_t* m, const float* cons
     if (p->ops[i].in1 >= 0) last[p->ops[i].in1] = i;
   }
   last[p->out_buf] = no;
+  const DevoxFusion fu = devox_fusion(p);
+  std::vector<char> virt(nb, 0);  // outputs of folded devoxelize ops: never in memory
+  for (int j = 0; j < no; ++j)
+    if (fu.fused[j] >= 0) {
+      const lt_net_op_t& d = p->ops[fu.fused[j]];
+      virt[d.out] = 1;
+      if (last[d.in0] < j) last[d.in0] = j;  // the voxel rows are read by the apply kernel of op j
+    }
   Pool pool;
   const int64_t shared_stat = keep ? -1 : pool.take(al64(2 * 1024));
   int64_t wsb = 256;
@@ -222,7 +272,9 @@ int fwd_layout(const lt_net_prog_t* p, const lt_net_maps_t* m, const float* cons
     const lt_net_op_t& op = p->ops[i];
     LT_REQUIRE(!(ext && ext[op.out]), LT_ERR_ARG, "lt_net: op %d writes the external buffer %d", i, op.out);
     for (int b : {op.in0, op.in1})
-      LT_REQUIRE(b < 0 || (ext && ext[b]) || L->off[b] >= 0, LT_ERR_ARG, "lt_net: op %d reads buffer %d before any op wrote it", i, b);
+      LT_REQUIRE(b < 0 || (ext && ext[b]) || L->off[b] >= 0 || virt[b], LT_ERR_ARG,
+                 "lt_net: op %d reads buffer %d before any op wrote it", i, b);
+    if (fu.skip[i]) continue;  // folded into its reader: no buffer, and its input stays alive until that reader
     L->off[op.out] = pool.take(buf_floats(p, m, op.out));
     if (op.kind == LT_NET_CONV_BN) {
       const lt_net_layer_t& ly = p->layers[op.layer];
@@ -240,6 +292,10 @@ int fwd_layout(const lt_net_prog_t* p, const lt_net_maps_t* m, const float* cons
       const int ins[2] = {op.in0, op.in1 == op.in0 ? -1 : op.in1};
       for (int b : ins)
         if (b >= 0 && L->off[b] >= 0 && last[b] == i) pool.give(L->off[b], buf_floats(p, m, b));
+      if (fu.fused[i] >= 0) {  // ... and the voxel rows of the devoxelize folded into this op
+        const int vb = p->ops[fu.fused[i]].in0;
+        if (vb != op.in0 && L->off[vb] >= 0 && last[vb] == i) pool.give(L->off[vb], buf_floats(p, m, vb));
+      }
       if (last[op.out] < 0) pool.give(L->off[op.out], buf_floats(p, m, op.out));  // an output nobody reads
     }
   }
@@ -265,16 +321,6 @@ std::vector<char> grad_needed(const lt_net_prog_t* p) {
     need[op.out] = op.kind == LT_NET_CONV_BN || need[op.in0] || (op.in1 >= 0 && need[op.in1]);
   }
   return need;
-}
-
-// how many ops read each buffer
-std::vector<int> reader_count(const lt_net_prog_t* p) {
-  std::vector<int> n(p->n_bufs, 0);
-  for (int i = 0; i < p->n_ops; ++i) {
-    ++n[p->ops[i].in0];
-    if (p->ops[i].in1 >= 0 && p->ops[i].in1 != p->ops[i].in0) ++n[p->ops[i].in1];
-  }
-  return n;
 }
 
 // relu = 3 (out = relu(bn(conv(in0))) + in1): the addend's gradient IS the output's.  When this op is the addend's only
@@ -359,10 +405,18 @@ extern "C" int lt_net_forward(const lt_net_prog_t* p, const lt_net_maps_t* m, co
              (long long)arena_floats);
   void* ws = arena + L.ws;
   auto ptr = [&](int b) -> const float* { return (ext && ext[b]) ? ext[b] : arena + L.off[b]; };
-  for (int b = 0; b < p->n_bufs; ++b)
-    LT_REQUIRE((ext && ext[b]) || L.off[b] >= 0, LT_ERR_ARG, "lt_net_forward: buffer %d is neither written by an op nor external", b);
+  const DevoxFusion fu = devox_fusion(p);
+  {
+    std::vector<char> virt(p->n_bufs, 0);
+    for (int i = 0; i < p->n_ops; ++i)
+      if (fu.skip[i]) virt[p->ops[i].out] = 1;
+    for (int b = 0; b < p->n_bufs; ++b)
+      LT_REQUIRE((ext && ext[b]) || L.off[b] >= 0 || virt[b], LT_ERR_ARG,
+                 "lt_net_forward: buffer %d is neither written by an op nor external", b);
+  }
   for (int i = 0; i < p->n_ops; ++i) {
     const lt_net_op_t& op = p->ops[i];
+    if (fu.skip[i]) continue;  // a devoxelize folded into the apply kernel of its reader
     const float* x = ptr(op.in0);
     float* y = arena + L.off[op.out];
     const int C = p->bufs[op.out].channels;
@@ -390,6 +444,17 @@ extern "C" int lt_net_forward(const lt_net_prog_t* p, const lt_net_maps_t* m, co
         float* co = keep ? arena + L.aux[i] : y;  // forward only: BatchNorm is applied in place on the conv output
         float* mean = arena + L.stat[i];
         float* var = mean + ly.cout;
+        if (fu.fused[i] >= 0) {
+          // out = relu(bn(conv(in0))) + devox(voxel rows): the addend is formed inside the apply kernel
+          const lt_net_op_t& d = p->ops[fu.fused[i]];
+          int64_t nb = 0;
+          rc = lt_spconv_plan_fwd_stats_nb(x, ly.w_fwd, g.plan, co, g.Vin, g.Vout, ly.cin, ly.cout, ly.K, ws, &nb, stream);
+          if (!rc) rc = lt_bn_finalize_sums_nb(ws, nb, g.Vout, ly.cout, mean, var, stream);
+          if (!rc)
+            rc = lt_bn_apply_devox(co, mean, var, ly.gamma, ly.beta, ly.eps, ptr(d.in0), m->v2p_idx[d.level], m->v2p_w[d.level],
+                                   y, m->n_points, ly.cout, m->n_vox[d.level], stream);
+          break;
+        }
         const float* res = op.in1 >= 0 ? ptr(op.in1) : nullptr;
         if (op.map == LT_NET_MAP_STEM) {
           rc = lt_spconv_stem_fwd(x, ly.w_fwd, g.plan, co, g.Vin, g.Vout, ly.cin, ly.cout, ly.K, stream);

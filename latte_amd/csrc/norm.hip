@@ -453,6 +453,84 @@ extern "C" int lt_bn_apply(const float* x, const float* mean, const float* var, 
   return LT_OK;
 }
 
+// y[p,:] = relu(bn(x[p,:])) + sum_{k<8} w[p,k] * vox[idx[p,k],:]  -- the point branch of SPVCNN with the devoxelized
+// features (latte/models/spvcnn.py:141-142,152-153,163-164: z.F = voxel_to_point(...).F + point_transforms(z.F)) summed in
+// ON THE FLY: the [points, C] devoxelized tensor is neither written nor read back (2 x 4NC bytes per pass; the voxel rows
+// come out of the caches).  Same arithmetic as lt_devoxelize_fwd followed by lt_bn_apply(relu = 3): the trilinear sum in
+// corner order with separate multiply and add, then one add -- bit-equal to the two-kernel path.
+__global__ __launch_bounds__(256) void k_bn_apply_devox(const float* __restrict__ x, const float* __restrict__ mean,
+                                                        const float* __restrict__ var, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps,
+                                                        const float* __restrict__ vox, const int* __restrict__ idx,
+                                                        const float* __restrict__ w, float* __restrict__ y, int64_t n4,
+                                                        int cg_n, int64_t V) {
+#pragma clang fp contract(off)
+  const int64_t stride = (int64_t)gridDim.x * 256;  // a multiple of cg_n (bn_ew_grid)
+  int64_t e = blockIdx.x * (int64_t)256 + threadIdx.x;
+  const int cg = (int)(e % cg_n);
+  const float4 m = reinterpret_cast<const float4*>(mean)[cg];
+  const float4 vr = reinterpret_cast<const float4*>(var)[cg];
+  const float4 g = reinterpret_cast<const float4*>(gamma)[cg];
+  const float4 b = reinterpret_cast<const float4*>(beta)[cg];
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  float4* y4 = reinterpret_cast<float4*>(y);
+  for (; e < n4; e += 2 * stride) {
+    const int64_t e1 = e + stride;
+    const bool two = e1 < n4;
+    const int64_t p0 = e / cg_n, p1 = two ? e1 / cg_n : p0;
+    const float4 v0 = x4[e];
+    const float4 v1 = two ? x4[e1] : v0;
+    // corner rows and weights of the two points (every lane of a row reads the same 64 B: one cache line per point)
+    const int4 ia0 = reinterpret_cast<const int4*>(idx + p0 * 8)[0], ib0 = reinterpret_cast<const int4*>(idx + p0 * 8)[1];
+    const float4 wa0 = reinterpret_cast<const float4*>(w + p0 * 8)[0], wb0 = reinterpret_cast<const float4*>(w + p0 * 8)[1];
+    const int4 ia1 = reinterpret_cast<const int4*>(idx + p1 * 8)[0], ib1 = reinterpret_cast<const int4*>(idx + p1 * 8)[1];
+    const float4 wa1 = reinterpret_cast<const float4*>(w + p1 * 8)[0], wb1 = reinterpret_cast<const float4*>(w + p1 * 8)[1];
+    const int i0[8] = {ia0.x, ia0.y, ia0.z, ia0.w, ib0.x, ib0.y, ib0.z, ib0.w};
+    const float w0[8] = {wa0.x, wa0.y, wa0.z, wa0.w, wb0.x, wb0.y, wb0.z, wb0.w};
+    const int i1[8] = {ia1.x, ia1.y, ia1.z, ia1.w, ib1.x, ib1.y, ib1.z, ib1.w};
+    const float w1[8] = {wa1.x, wa1.y, wa1.z, wa1.w, wb1.x, wb1.y, wb1.z, wb1.w};
+    float4 f0[8], f1[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      f0[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      f1[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i0[k] >= 0 && i0[k] < V) f0[k] = reinterpret_cast<const float4*>(vox + (int64_t)i0[k] * cg_n * 4)[cg];
+      if (two && i1[k] >= 0 && i1[k] < V) f1[k] = reinterpret_cast<const float4*>(vox + (int64_t)i1[k] * cg_n * 4)[cg];
+    }
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      a0.x += w0[k] * f0[k].x; a0.y += w0[k] * f0[k].y; a0.z += w0[k] * f0[k].z; a0.w += w0[k] * f0[k].w;
+      a1.x += w1[k] * f1[k].x; a1.y += w1[k] * f1[k].y; a1.z += w1[k] * f1[k].z; a1.w += w1[k] * f1[k].w;
+    }
+    float4 o = bn_apply4(v0, m, vr, g, b, eps);
+    o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+    o.x += a0.x; o.y += a0.y; o.z += a0.z; o.w += a0.w;
+    y4[e] = o;
+    if (two) {
+      float4 q = bn_apply4(v1, m, vr, g, b, eps);
+      q.x = fmaxf(q.x, 0.f); q.y = fmaxf(q.y, 0.f); q.z = fmaxf(q.z, 0.f); q.w = fmaxf(q.w, 0.f);
+      q.x += a1.x; q.y += a1.y; q.z += a1.z; q.w += a1.w;
+      y4[e1] = q;
+    }
+  }
+}
+
+extern "C" int lt_bn_apply_devox(const float* x, const float* mean, const float* var, const float* gamma, const float* beta,
+                                 float eps, const float* vox, const int32_t* idx, const float* w, float* y, int64_t N,
+                                 int32_t C, int64_t V, hipStream_t stream) {
+  int rc = check_vc("lt_bn_apply_devox", N, C);
+  if (rc) return rc;
+  LT_REQUIRE(x && mean && var && gamma && beta && y && idx && w && (V == 0 || vox) && V >= 0, LT_ERR_ARG,
+             "lt_bn_apply_devox: null pointer");
+  const int64_t n4 = N * (C / 4);
+  const dim3 grid(bn_ew_grid(n4, C / 4));
+  hipLaunchKernelGGL(k_bn_apply_devox, grid, dim3(256), 0, stream, x, mean, var, gamma, beta, eps, vox, idx, w, y, n4, C / 4,
+                     V);
+  LT_LAUNCH_CHECK();
+  return LT_OK;
+}
+
 extern "C" int lt_bn_bwd_reduce(const float* dy, const float* x, const float* y, const float* mean, const float* var,
                                 const float* gamma, const float* beta, float eps, int32_t relu, int64_t V, int32_t C,
                                 void* ws, int64_t ws_bytes, float* sum_g, float* sum_gx, hipStream_t stream) {

@@ -353,6 +353,21 @@ def bn_apply(x, mean, var, gamma, beta, eps: float, residual=None, relu: bool = 
     return y
 
 
+def bn_apply_devox(x, mean, var, gamma, beta, eps: float, vox, idx, w):
+    """relu(bn(x)) + devoxelize(vox, idx, w) in one kernel (lt_bn_apply_devox): x [N,C], vox [V,C], idx int32 [N,8], w [N,8]."""
+    x = _chk(x, torch.float32, "bn_apply_devox x")
+    vox = _chk(vox, torch.float32, "bn_apply_devox vox")
+    idx = _chk(idx, torch.int32, "bn_apply_devox idx")
+    w = _chk(w, torch.float32, "bn_apply_devox w")
+    N, C = x.shape
+    assert idx.shape == (N, 8) and w.shape == (N, 8) and vox.shape[1] == C
+    y = torch.empty_like(x)
+    _lib.call("lt_bn_apply_devox", _p(x), _p(mean), _p(var), _p(_chk(gamma.detach(), torch.float32, "gamma")),
+              _p(_chk(beta.detach(), torch.float32, "beta")), float(eps), _p(vox), _p(idx), _p(w), _p(y), N, int(C),
+              vox.shape[0], _stream())
+    return y
+
+
 def _relu_mode(relu: bool, y, beta) -> int:
     """0 = no ReLU; 1 = mask from the saved output y; 2 = no y saved (the forward added no residual): the kernels rebuild
     the mask from x, gamma, beta with the forward's own expression"""

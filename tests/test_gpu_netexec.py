@@ -48,6 +48,23 @@ def test_identity_plan_runs_a_dense_product():
         assert rel_err(out, want) < 1e-6, rows
 
 
+@pytest.mark.parametrize("C", [32, 96, 256])
+def test_apply_with_the_devoxelized_addend_formed_on_the_fly_is_bit_equal(C):
+    """lt_bn_apply_devox == lt_devoxelize_fwd then lt_bn_apply(relu = 3); missing corners, odd row counts"""
+    from latte_amd import ops
+    torch.manual_seed(C)
+    for N, V in ((1, 5), (777, 100), (20001, 3000)):
+        x = torch.randn(N, C, device="cuda")
+        vox = torch.randn(V, C, device="cuda")
+        idx = torch.randint(-1, V, (N, 8), device="cuda", dtype=torch.int32)
+        w = torch.rand(N, 8, device="cuda")
+        gamma, beta = torch.rand(C, device="cuda") + 0.5, torch.randn(C, device="cuda")
+        mean, var = ops.bn_stats(x)
+        want = ops.bn_apply(x, mean, var, gamma, beta, 1e-5, residual=ops.devoxelize_fwd(vox, idx, w), relu=True, post_add=True)
+        got = ops.bn_apply_devox(x, mean, var, gamma, beta, 1e-5, vox, idx, w)
+        assert torch.equal(got, want), (N, V)
+
+
 @pytest.mark.parametrize("cr", [0.5, 1.0])
 def test_one_call_forward_matches_the_module_path(scans_small, cr):
     m = tta_model(cr)
