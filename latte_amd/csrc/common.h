@@ -125,6 +125,9 @@ int lt_spconv_plan_fwd_stats_nb(const float* in, const float* packed, const void
                                 int32_t Cin, int32_t Cout, int32_t K, void* stats_ws, int64_t* nb, hipStream_t stream);
 // lt_bn_finalize_sums over an explicit number of partial rows
 int lt_bn_finalize_sums_nb(void* stats_ws, int64_t nb, int64_t V, int32_t C, float* mean, float* var, hipStream_t stream);
+// lt_voxelize_bwd over float4 column groups; accumulate != 0: gfeats += (the gradient of a tensor with a second reader)
+int lt_voxelize_bwd_acc(const float* gout, const int32_t* idx, const int32_t* counts, float* gfeats, int64_t N, int32_t C,
+                        int64_t V, int accumulate, hipStream_t stream);
 #endif
 
 // ---- device helpers -------------------------------------------------------

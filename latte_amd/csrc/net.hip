@@ -542,9 +542,10 @@ extern "C" int lt_net_backward(const lt_net_prog_t* p, const lt_net_maps_t* m, c
           if (need[op.in0]) {
             LT_REQUIRE(m->p2v_idx[op.level] && m->p2v_counts[op.level], LT_ERR_ARG,
                        "lt_net_backward: no point->voxel index / counts on level %d", op.level);
-            float* dst = written[op.in0] ? tmp[0] : gptr(op.in0);
-            rc = lt_voxelize_bwd(dy, m->p2v_idx[op.level], m->p2v_counts[op.level], dst, m->n_points, C, m->n_vox[op.level], stream);
-            if (!rc && written[op.in0]) rc = launch_add(gptr(op.in0), dst, m->n_points * (int64_t)C, stream);
+            // a second contribution is added in place by the gather itself (the point tensors are the largest of the pass:
+            // a temporary and an add would move 3 x 4NC bytes more)
+            rc = lt_voxelize_bwd_acc(dy, m->p2v_idx[op.level], m->p2v_counts[op.level], gptr(op.in0), m->n_points, C,
+                                     m->n_vox[op.level], (int)written[op.in0], stream);
             written[op.in0] = 1;
           }
           break;

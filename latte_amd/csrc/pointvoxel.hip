@@ -37,6 +37,43 @@ __global__ void k_voxelize_bwd(const float* __restrict__ g, const int* __restric
   }
 }
 
+// the same gather over float4 column groups, optionally ADDED to what gf already holds (the gradient of a tensor with a
+// second reader: lt_net_backward) -- same value per element as the scalar kernel, then one add
+__global__ void k_voxelize_bwd4(const float4* __restrict__ g, const int* __restrict__ idx, const int* __restrict__ counts,
+                                float4* __restrict__ gf, int64_t N, int C4, int64_t V, int acc) {
+  const int64_t total = N * (int64_t)C4;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = e / C4;
+    const int c = (int)(e - i * C4);
+    const int pos = idx[i];
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (pos >= 0 && pos < V) {
+      const int cnt = counts[pos];
+      if (cnt > 0) {
+        const float4 t = g[(int64_t)pos * C4 + c];
+        const float d = (float)cnt;
+        v = make_float4(t.x / d, t.y / d, t.z / d, t.w / d);
+      }
+    }
+    if (acc) {
+      const float4 o = gf[e];
+      v = make_float4(o.x + v.x, o.y + v.y, o.z + v.z, o.w + v.w);
+    }
+    gf[e] = v;
+  }
+}
+
+int lt_voxelize_bwd_acc(const float* gout, const int32_t* idx, const int32_t* counts, float* gfeats, int64_t N, int32_t C,
+                        int64_t V, int accumulate, hipStream_t stream) {
+  LT_REQUIRE(N >= 0 && V >= 0 && C >= 4 && C % 4 == 0, LT_ERR_ARG, "lt_voxelize_bwd_acc: bad sizes (C %% 4 == 0)");
+  if (N == 0) return LT_OK;
+  LT_REQUIRE(gfeats && idx && counts && (V == 0 || gout), LT_ERR_ARG, "lt_voxelize_bwd_acc: null pointer");
+  hipLaunchKernelGGL(k_voxelize_bwd4, dim3(lt_grid(N * (C / 4), 256)), dim3(256), 0, stream, (const float4*)gout, idx, counts,
+                     (float4*)gfeats, N, C / 4, V, accumulate);
+  LT_LAUNCH_CHECK();
+  return LT_OK;
+}
+
 extern "C" int lt_voxelize_fwd(const float* feats, const int32_t* idx, const int32_t* counts, float* out, int64_t N,
                                int32_t C, int64_t V, hipStream_t stream) {
   LT_REQUIRE(N >= 0 && V >= 0 && C >= 1, LT_ERR_ARG, "lt_voxelize_fwd: bad sizes");
