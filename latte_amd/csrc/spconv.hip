@@ -1412,6 +1412,15 @@ static bool conv_ls_default(int64_t Vin, int64_t Vout, int Cin, int Cout, int K)
     const char* e = getenv("LT_CONV_LS");
     return e ? atoi(e) : 1;
   }();
+  if (K == 1 && Vin == Vout && g_conv_precision == 0) {
+    // dense layers over an identity plan (lt_kmap_plan_identity): ONE offset for the whole launch -- the weights are staged
+    // once per workgroup and stay; LT_CONV_LS_DENSE=0 keeps them on the split-j kernel (A/B)
+    static const int dense = [] {
+      const char* e = getenv("LT_CONV_LS_DENSE");
+      return e ? atoi(e) : 1;
+    }();
+    return dense != 0 && lt_spconv_ls_supported(Vin, Vout, Cin, Cout, K);
+  }
   if (mode == 0 || K > 8 || K < 2 || Vout <= Vin || g_conv_precision != 0) return false;
   return lt_spconv_ls_supported(Vin, Vout, Cin, Cout, K);
 }
