@@ -344,12 +344,19 @@ class _NetFn(Function):
         return (None, None, None, None) + tuple(grads)
 
 
+def wants_grad(prog: NetProgram) -> bool:
+    """Will a pass issued now be differentiated?  (BatchNorm affine parameters are the only trainable ones here.)"""
+    return torch.is_grad_enabled() and any(bn.weight.requires_grad or bn.bias.requires_grad for _, bn, _ in prog.mods)
+
+
 def run(prog: NetProgram, feats: torch.Tensor, maps: BatchMaps, levels: dict) -> torch.Tensor:
     feats = feats.contiguous()
     if ops.CONV_PAIRS is not None:
         ops.CONV_PAIRS.extend(prog.conv_pairs(levels, maps, backward=False))
-    if not torch.is_grad_enabled() or not any(bn.weight.requires_grad or bn.bias.requires_grad for _, bn, _ in prog.mods):
+    if not wants_grad(prog):
         return prog.forward(feats, maps, keep=False)[0]
+    if not maps.struct.v2p_perm[0]:
+        raise RuntimeError("netprog.run: the batch was prepared without the backward's CSRs (SPVCNN.prepare(backward=True))")
     params = []
     for _, bn, _ in prog.mods:
         params.append(bn.weight)

@@ -247,11 +247,17 @@ class SPVCNN(nn.Module):
             # the library (netprog.py / lt_net_forward); everything else walks the module tree below
             prog = self._program()
             if prog.eligible(x.feats):
-                self.prepare(x, backward=True)
-                cache, _ = self._batch_cache(x)
+                from . import netprog
+                need_bwd = netprog.wants_grad(prog)
+                self.prepare(x, backward=need_bwd)
+                cache, z = self._batch_cache(x)
                 maps = cache.get("net_maps")
-                if maps is not None and maps.struct.v2p_perm[0]:
-                    from . import netprog
+                if maps is not None and need_bwd and not maps.struct.v2p_perm[0]:
+                    # the batch was prepared for inference only: add what the backward reads
+                    for s in (1, 16, 4):
+                        v2p_csr(cache["levels"][s], z)
+                    maps = cache["net_maps"] = netprog.build_maps(cache, z, cache["levels"])
+                if maps is not None:
                     return netprog.run(prog, x.feats, maps, cache["levels"])
         return self._forward_modules(x)
 

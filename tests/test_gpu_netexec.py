@@ -187,6 +187,33 @@ def test_one_call_backward_matches_the_module_path(scans_small):
     assert errs[-1] < 3e-2 and errs[len(errs) // 2] < 1e-2, (errs[-1], errs[len(errs) // 2])
 
 
+def test_batch_prepared_for_inference_gets_the_backward_structures_on_demand(scans_small):
+    """a no-grad pass does not build the devoxelize CSRs; a differentiated pass over the SAME batch adds them and gives
+    the gradients of a batch that had them from the start"""
+    m = tta_model(0.5)
+    net = m.net_3d
+    lidar = lidar_of(scans_small)
+    with torch.no_grad():
+        a = net(lidar)
+    cache, z = net._batch_cache(lidar)
+    assert not cache["net_maps"].struct.v2p_perm[0] and "v2p_csr" not in z.additional_features
+    torch.manual_seed(5)
+    wgt = torch.randn_like(a)
+    out = net(lidar)
+    assert cache["net_maps"].struct.v2p_perm[0]
+    assert torch.equal(out.detach(), a)
+    (out * wgt).sum().backward()
+    got = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+    for p in net.parameters():
+        p.grad = None
+    fresh = lidar_of(scans_small)
+    (net(fresh) * wgt).sum().backward()
+    assert len(got) == 2 * 52
+    for n, p in net.named_parameters():
+        if p.grad is not None:
+            assert torch.equal(got[n], p.grad), n
+
+
 def test_program_is_not_copied_with_the_model(scans_small):
     m = tta_model(0.5)
     lidar = lidar_of(scans_small)
