@@ -81,8 +81,7 @@ typedef struct {           /* index structures of one batch; device pointers */
   const int32_t* p2v_counts[5];
   const int32_t* v2p_idx[5];    /* [n_points, 8] corner rows and trilinear weights: lt_devoxelize_fwd */
   const float* v2p_w[5];
-  const int32_t* v2p_perm[5];   /* lt_csr_build of v2p_idx flattened: lt_devoxelize_csr_bwd (backward only) */
-  const int32_t* v2p_off[5];
+  const int32_t* v2p_cells[5];  /* lt_devoxelize_cells over the level's p2v CSR: lt_devoxelize_cell_bwd (backward only) */
 } lt_net_maps_t;
 
 /* Identity plan (K = 1, row i reads row i): what a 1x1x1 conv / nn.Linear needs to run through lt_spconv_plan_fwd*

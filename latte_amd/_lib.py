@@ -82,6 +82,8 @@ SIGNATURES = {
     "lt_csr_build": (ctypes.c_int, [P, I64, I64, P, I64, P, P, P]),
     "lt_voxelize_csr_fwd": (ctypes.c_int, [P, P, P, P, I64, I32, P]),
     "lt_devoxelize_csr_bwd": (ctypes.c_int, [P, P, P, P, P, I64, I32, P]),
+    "lt_devoxelize_cells": (ctypes.c_int, [P, P, P, P, I64, I64, I64, P]),
+    "lt_devoxelize_cell_bwd": (ctypes.c_int, [P, P, P, P, P, P, P, P, I64, I64, I32, P]),
     # include/latte_hip_st.h
     "lt_softmax_entropy": (ctypes.c_int, [P, I64, I32, P, P, P]),
     "lt_softmax_bwd": (ctypes.c_int, [P, P, I64, I32, P, P]),
@@ -126,7 +128,7 @@ class NetProg(ctypes.Structure):
 class NetMaps(ctypes.Structure):
     _fields_ = [("n_points", I64), ("n_vox", I64 * 5), ("plan_k3", P * 5), ("plan_down", P * 4), ("plan_up", P * 4),
                 ("plan_dense", P * 6), ("p2v_perm", P * 5), ("p2v_off", P * 5), ("p2v_idx", P * 5), ("p2v_counts", P * 5),
-                ("v2p_idx", P * 5), ("v2p_w", P * 5), ("v2p_perm", P * 5), ("v2p_off", P * 5)]
+                ("v2p_idx", P * 5), ("v2p_w", P * 5), ("v2p_cells", P * 5)]
 
 
 _SIGS = {

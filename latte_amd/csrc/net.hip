@@ -551,11 +551,13 @@ extern "C" int lt_net_backward(const lt_net_prog_t* p, const lt_net_maps_t* m, c
           break;
         case LT_NET_DEVOX:
           if (need[op.in0]) {
-            LT_REQUIRE(m->v2p_perm[op.level] && m->v2p_off[op.level], LT_ERR_ARG,
-                       "lt_net_backward: no CSR of the voxel->point map on level %d", op.level);
+            LT_REQUIRE(m->v2p_cells[op.level] && m->p2v_perm[op.level] && m->p2v_off[op.level] && m->p2v_idx[op.level],
+                       LT_ERR_ARG, "lt_net_backward: no cell table / point->voxel CSR for the voxel->point map on level %d",
+                       op.level);
             float* dst = written[op.in0] ? tmp[0] : gptr(op.in0);
-            rc = lt_devoxelize_csr_bwd(dy, m->v2p_perm[op.level], m->v2p_off[op.level], m->v2p_w[op.level], dst,
-                                       m->n_vox[op.level], C, stream);
+            rc = lt_devoxelize_cell_bwd(dy, m->v2p_cells[op.level], m->p2v_perm[op.level], m->p2v_off[op.level],
+                                        m->p2v_idx[op.level], m->v2p_idx[op.level], m->v2p_w[op.level], dst, m->n_points,
+                                        m->n_vox[op.level], C, stream);
             if (!rc && written[op.in0]) rc = launch_add(gptr(op.in0), dst, m->n_vox[op.level] * (int64_t)C, stream);
             written[op.in0] = 1;
           }

@@ -351,3 +351,112 @@ extern "C" int lt_devoxelize_csr_bwd(const float* gout, const int32_t* perm, con
   LT_LAUNCH_CHECK();
   return LT_OK;
 }
+
+// ---------------------------------------------------------------- devoxelize backward over the point -> voxel CSR
+// All points of one cell u (floor(z.C / s): the point -> voxel map of the level) query the same 8 corner hashes, so they
+// share their corner voxels: idx[p, c] = corner_c(u).  The points that touch voxel v through corner c are therefore the
+// points of ONE cell, cells[v, c], and the backward needs no CSR of its own (lt_csr_build over 8N keys: three radix sorts
+// of 6.3 M keys per batch at the a2d2 sizes) -- only this [V, 8] table, filled from the first point of every cell.
+__global__ void k_devox_cells(const int* __restrict__ idx, const int* __restrict__ pperm, const int* __restrict__ poff,
+                              int* __restrict__ cells, int64_t Vp, int64_t V) {
+  const int64_t total = Vp * 8;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t u = e >> 3;
+    const int c = (int)(e & 7);
+    const int j0 = poff[u];
+    if (poff[u + 1] <= j0) continue;
+    const int v = idx[(int64_t)pperm[j0] * 8 + c];
+    if (v >= 0 && v < V) cells[(int64_t)v * 8 + c] = (int)u;  // one writer: u = the cell at v - offset_c
+  }
+}
+
+// gfeats[v,:] = sum_c sum_{p in cell cells[v,c], ascending} w[p,c] * gout[p,:]
+__global__ void k_devox_cell_bwd(const float* __restrict__ g, const int* __restrict__ cells, const int* __restrict__ pperm,
+                                 const int* __restrict__ poff, const float* __restrict__ w, float* __restrict__ gf, int64_t V,
+                                 int C4) {
+#pragma clang fp contract(off)
+  const int64_t total = V * (int64_t)C4;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t v = e / C4;
+    const int c4 = (int)(e - v * C4);
+    const int4 ua = reinterpret_cast<const int4*>(cells)[v * 2], ub = reinterpret_cast<const int4*>(cells)[v * 2 + 1];
+    const int u[8] = {ua.x, ua.y, ua.z, ua.w, ub.x, ub.y, ub.z, ub.w};
+    int j0[8], j1[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      j0[c] = u[c] >= 0 ? poff[u[c]] : 0;
+      j1[c] = u[c] >= 0 ? poff[u[c] + 1] : 0;
+    }
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      int j = j0[c];
+      for (; j + 4 <= j1[c]; j += 4) {  // 4 gathers in flight, adds in ascending point order
+        const int p0 = pperm[j], p1 = pperm[j + 1], p2 = pperm[j + 2], p3 = pperm[j + 3];
+        const float w0 = w[(int64_t)p0 * 8 + c], w1 = w[(int64_t)p1 * 8 + c], w2 = w[(int64_t)p2 * 8 + c],
+                    w3 = w[(int64_t)p3 * 8 + c];
+        const float4 x0 = reinterpret_cast<const float4*>(g + (int64_t)p0 * C4 * 4)[c4];
+        const float4 x1 = reinterpret_cast<const float4*>(g + (int64_t)p1 * C4 * 4)[c4];
+        const float4 x2 = reinterpret_cast<const float4*>(g + (int64_t)p2 * C4 * 4)[c4];
+        const float4 x3 = reinterpret_cast<const float4*>(g + (int64_t)p3 * C4 * 4)[c4];
+        acc.x += w0 * x0.x; acc.y += w0 * x0.y; acc.z += w0 * x0.z; acc.w += w0 * x0.w;
+        acc.x += w1 * x1.x; acc.y += w1 * x1.y; acc.z += w1 * x1.z; acc.w += w1 * x1.w;
+        acc.x += w2 * x2.x; acc.y += w2 * x2.y; acc.z += w2 * x2.z; acc.w += w2 * x2.w;
+        acc.x += w3 * x3.x; acc.y += w3 * x3.y; acc.z += w3 * x3.z; acc.w += w3 * x3.w;
+      }
+      for (; j < j1[c]; ++j) {
+        const int p = pperm[j];
+        const float wk = w[(int64_t)p * 8 + c];
+        const float4 x = reinterpret_cast<const float4*>(g + (int64_t)p * C4 * 4)[c4];
+        acc.x += wk * x.x; acc.y += wk * x.y; acc.z += wk * x.z; acc.w += wk * x.w;
+      }
+    }
+    reinterpret_cast<float4*>(gf)[e] = acc;
+  }
+}
+
+// points whose cell is not a voxel of the level (pidx < 0: never with SPVCNN, whose coarse levels contain every point's
+// cell) are in no CSR row: their contributions are added here, atomically
+__global__ void k_devox_unmapped(const float* __restrict__ g, const int* __restrict__ pidx, const int* __restrict__ idx,
+                                 const float* __restrict__ w, float* __restrict__ gf, int64_t N, int64_t V, int C) {
+  for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < N; p += (int64_t)gridDim.x * blockDim.x) {
+    if (pidx[p] >= 0) continue;
+    for (int c = 0; c < 8; ++c) {
+      const int v = idx[p * 8 + c];
+      if (v < 0 || v >= V) continue;
+      const float wk = w[p * 8 + c];
+      for (int ch = 0; ch < C; ++ch) atomicAdd(gf + (int64_t)v * C + ch, wk * g[p * C + ch]);
+    }
+  }
+}
+
+extern "C" int lt_devoxelize_cells(const int32_t* v2p_idx, const int32_t* p2v_perm, const int32_t* p2v_off, int32_t* cells,
+                                   int64_t N, int64_t Vp, int64_t V, hipStream_t stream) {
+  LT_REQUIRE(N >= 0 && Vp >= 0 && V >= 0, LT_ERR_ARG, "lt_devoxelize_cells: bad sizes");
+  if (V == 0) return LT_OK;
+  LT_REQUIRE(cells, LT_ERR_ARG, "lt_devoxelize_cells: null pointer");
+  LT_CHECK_HIP(hipMemsetAsync(cells, 0xFF, V * 8 * sizeof(int32_t), stream));
+  if (N == 0 || Vp == 0) return LT_OK;
+  LT_REQUIRE(v2p_idx && p2v_perm && p2v_off, LT_ERR_ARG, "lt_devoxelize_cells: null pointer");
+  hipLaunchKernelGGL(k_devox_cells, dim3(lt_grid(Vp * 8, 256)), dim3(256), 0, stream, v2p_idx, p2v_perm, p2v_off, cells, Vp, V);
+  LT_LAUNCH_CHECK();
+  return LT_OK;
+}
+
+extern "C" int lt_devoxelize_cell_bwd(const float* gout, const int32_t* cells, const int32_t* p2v_perm,
+                                      const int32_t* p2v_off, const int32_t* p2v_idx, const int32_t* v2p_idx, const float* w,
+                                      float* gfeats, int64_t N, int64_t V, int32_t C, hipStream_t stream) {
+  LT_REQUIRE(N >= 0 && V >= 0 && C >= 4 && C % 4 == 0, LT_ERR_ARG, "lt_devoxelize_cell_bwd: bad sizes (C %% 4 == 0 required)");
+  if (V == 0) return LT_OK;
+  LT_REQUIRE(gout && cells && p2v_perm && p2v_off && p2v_idx && v2p_idx && w && gfeats, LT_ERR_ARG,
+             "lt_devoxelize_cell_bwd: null pointer");
+  hipLaunchKernelGGL(k_devox_cell_bwd, dim3(lt_grid(V * (C / 4), 256)), dim3(256), 0, stream, gout, cells, p2v_perm, p2v_off,
+                     w, gfeats, V, C / 4);
+  LT_LAUNCH_CHECK();
+  if (N > 0) {
+    hipLaunchKernelGGL(k_devox_unmapped, dim3(lt_grid(N, 256)), dim3(256), 0, stream, gout, p2v_idx, v2p_idx, w, gfeats, N, V,
+                       C);
+    LT_LAUNCH_CHECK();
+  }
+  return LT_OK;
+}

@@ -554,11 +554,14 @@ class _Devoxelize(Function):
         idx, w = ctx.saved_tensors
         csr = ctx.csr() if callable(ctx.csr) else ctx.csr
         if csr is not None and gout.shape[1] % 4 == 0:
+            if len(csr) == 3:   # (cells, point->voxel CSR, point->voxel index): no CSR of this map needed
+                return ops.devoxelize_cell_bwd(gout.contiguous(), csr[0], csr[1], csr[2], idx, w), None, None, None
             return ops.devoxelize_csr_bwd(gout.contiguous(), csr, w, ctx.v), None, None, None
         return ops.devoxelize_bwd(gout.contiguous(), idx, w, ctx.v), None, None, None
 
 
 def spdevoxelize(feats, idx, w, csr=None):
     """F.spdevoxelize (latte/models/torchsparse_utils.py:81,93); idx [N,8] any int dtype, w [N,8] fp32.  csr (optional):
-    ops.csr_build(idx.view(-1), V) of this map, or a callable returning it -> the atomic-free backward kernel."""
+    ops.csr_build(idx.view(-1), V) of this map, or (ops.devoxelize_cells table, the point->voxel CSR of the level, the
+    point->voxel index), or a callable returning either -> an atomic-free backward kernel."""
     return _Devoxelize.apply(feats.contiguous(), _i32(idx), w.contiguous(), csr)

@@ -80,9 +80,9 @@ def build_maps(cache: dict, z, levels: dict) -> BatchMaps:
         m.p2v_counts[l] = ptr(LF._i32(af["counts"][s3]))
         m.v2p_idx[l] = ptr(LF._i32(z.idx_query[s3]))
         m.v2p_w[l] = ptr(z.weights[s3].contiguous())
-        csr = af.get("v2p_csr", {}).get(s3)
-        if csr is not None:
-            m.v2p_perm[l], m.v2p_off[l] = ptr(csr[0]), ptr(csr[1])
+        cells = af.get("v2p_cells", {}).get(s3)
+        if cells is not None:
+            m.v2p_cells[l] = ptr(cells)
     return BatchMaps(m, keep, int(m.n_points), [int(v) for v in m.n_vox])
 
 
@@ -355,8 +355,8 @@ def run(prog: NetProgram, feats: torch.Tensor, maps: BatchMaps, levels: dict) ->
         ops.CONV_PAIRS.extend(prog.conv_pairs(levels, maps, backward=False))
     if not wants_grad(prog):
         return prog.forward(feats, maps, keep=False)[0]
-    if not maps.struct.v2p_perm[0]:
-        raise RuntimeError("netprog.run: the batch was prepared without the backward's CSRs (SPVCNN.prepare(backward=True))")
+    if not maps.struct.v2p_cells[0]:
+        raise RuntimeError("netprog.run: the batch was prepared without the backward's tables (SPVCNN.prepare(backward=True))")
     params = []
     for _, bn, _ in prog.mods:
         params.append(bn.weight)

@@ -14,7 +14,7 @@ from . import _lib
 __all__ = [
     "sphash", "HashTable", "sphashquery", "spcount", "unique_sorted", "pack_xyz_keys", "downsample_coords",
     "kmap_build", "kmap_pairs", "kmap_reverse", "kmap_order", "kmap_plan", "spconv_plan", "pack_weights", "spconv", "bn_stats", "bn_apply",
-    "bn_bwd", "voxelize_fwd", "voxelize_bwd", "calc_ti_weights", "devoxelize_fwd", "devoxelize_bwd", "csr_build", "voxelize_csr_fwd", "devoxelize_csr_bwd",
+    "bn_bwd", "voxelize_fwd", "voxelize_bwd", "calc_ti_weights", "devoxelize_fwd", "devoxelize_bwd", "csr_build", "voxelize_csr_fwd", "devoxelize_csr_bwd", "devoxelize_cells", "devoxelize_cell_bwd",
 ]
 
 
@@ -458,6 +458,31 @@ def devoxelize_csr_bwd(gout, csr, w, V: int):
     C = gout.shape[1]
     gf = torch.empty((V, C), dtype=torch.float32, device=gout.device)
     _lib.call("lt_devoxelize_csr_bwd", _p(gout), _p(perm), _p(off), _p(w), _p(gf), V, C, _stream())
+    return gf
+
+
+def devoxelize_cells(v2p_idx, p2v_csr, V: int):
+    """lt_devoxelize_cells: [V, 8] table "which cell reaches voxel v through corner c" from the point -> voxel CSR."""
+    v2p_idx = _chk(v2p_idx, torch.int32, "devox_cells idx")
+    perm, off = p2v_csr
+    N = v2p_idx.shape[0]
+    assert v2p_idx.shape[1] == 8 and perm.numel() <= N
+    cells = torch.empty((V, 8), dtype=torch.int32, device=v2p_idx.device)
+    _lib.call("lt_devoxelize_cells", _p(v2p_idx), _p(perm), _p(off), _p(cells), N, off.numel() - 1, V, _stream())
+    return cells
+
+
+def devoxelize_cell_bwd(gout, cells, p2v_csr, p2v_idx, v2p_idx, w):
+    gout = _chk(gout, torch.float32, "devox_bwd gout")
+    p2v_idx = _chk(p2v_idx, torch.int32, "devox_bwd p2v idx")
+    v2p_idx = _chk(v2p_idx, torch.int32, "devox_bwd v2p idx")
+    perm, off = p2v_csr
+    N, C = gout.shape
+    V = cells.shape[0]
+    assert p2v_idx.numel() == N and v2p_idx.numel() == 8 * N and w.numel() == 8 * N and w.is_contiguous()
+    gf = torch.empty((V, C), dtype=torch.float32, device=gout.device)
+    _lib.call("lt_devoxelize_cell_bwd", _p(gout), _p(cells), _p(perm), _p(off), _p(p2v_idx), _p(v2p_idx), _p(w), _p(gf), N, V,
+              C, _stream())
     return gf
 
 

@@ -9,7 +9,7 @@ from . import functional as LF
 from . import ops
 from .tensor import PointTensor, SparseTensor
 
-__all__ = ["initial_voxelize", "point_to_voxel", "voxel_to_point", "p2v_index", "v2p_index", "v2p_csr"]
+__all__ = ["initial_voxelize", "point_to_voxel", "voxel_to_point", "p2v_index", "v2p_index", "v2p_cells"]
 
 
 def initial_voxelize(z: PointTensor, init_res: float, after_res: float, cache: dict | None = None) -> SparseTensor:
@@ -87,25 +87,32 @@ def v2p_index(x: SparseTensor, z: PointTensor, nearest: bool = False):
     return idx_query.int(), weights
 
 
-def _v2p_csr(af: dict, idx_query_of: dict, s, n_vox: int):
-    cs = af.setdefault("v2p_csr", {})
+def _v2p_cells(af: dict, idx_query_of: dict, s, n_vox: int):
+    """(cells, point->voxel CSR, point->voxel index) of stride s, or None when the level has no point->voxel map."""
+    cs = af.setdefault("v2p_cells", {})
     if cs.get(s) is None:
-        cs[s] = ops.csr_build(idx_query_of[s].reshape(-1), n_vox)
-    return cs[s]
+        p2v = af.get("p2v_csr", {}).get(s)
+        if p2v is None or af["idx_query"].get(s) is None:
+            return None
+        cs[s] = ops.devoxelize_cells(LF._i32(idx_query_of[s]), p2v, n_vox)
+    return cs[s], af["p2v_csr"][s], LF._i32(af["idx_query"][s])
 
 
-def v2p_csr(x: SparseTensor, z: PointTensor):
-    """CSR of the devoxelize map of stride x.s (entries 8*point + corner per voxel): the backward of spdevoxelize as an
-    atomic-free gather.  Built on first use and cached with the map."""
-    return _v2p_csr(z.additional_features, z.idx_query, x.s, x.C.shape[0])
+def v2p_cells(x: SparseTensor, z: PointTensor):
+    """What the backward of spdevoxelize at stride x.s gathers over (ops.devoxelize_cell_bwd): every point of a cell shares
+    its 8 corner voxels, so the point->voxel CSR of the level plus a [V, 8] table replaces a CSR of the 8N-entry map.
+    Built on first use and cached with the map; x's voxel set must be the one the point->voxel map was built on."""
+    p2v_index(x, z)
+    return _v2p_cells(z.additional_features, z.idx_query, x.s, x.C.shape[0])
 
 
 def voxel_to_point(x: SparseTensor, z: PointTensor, nearest: bool = False) -> PointTensor:
     csr = None
     if torch.is_grad_enabled() and x.F.requires_grad:
         # backward only: looked up (or built) when the gradient arrives
+        p2v_index(x, z)
         af, idxq, s, n_vox = z.additional_features, z.idx_query, x.s, x.C.shape[0]
-        csr = lambda: _v2p_csr(af, idxq, s, n_vox)
+        csr = lambda: _v2p_cells(af, idxq, s, n_vox)
     if z.idx_query is None or z.weights is None or z.idx_query.get(x.s) is None or z.weights.get(x.s) is None:
         idx_query, weights = v2p_index(x, z, nearest)
         new_feat = LF.spdevoxelize(x.F, idx_query, weights, csr)

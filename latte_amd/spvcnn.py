@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from . import sparse_modules as spnn
-from .point_voxel import initial_voxelize, p2v_index, point_to_voxel, v2p_csr, v2p_index, voxel_to_point
+from .point_voxel import initial_voxelize, p2v_index, point_to_voxel, v2p_cells, v2p_index, voxel_to_point
 from .tensor import PointTensor, SparseTensor, cat
 
 __all__ = ["SPVCNN", "Net3DSeg", "BasicConvolutionBlock", "BasicDeconvolutionBlock", "ResidualBlock",
@@ -226,7 +226,7 @@ class SPVCNN(nn.Module):
                 z.idx_query[levels[s].s], z.weights[levels[s].s] = v2p_index(levels[s], z)
             p2v_index(levels[s], z)
             if backward:
-                v2p_csr(levels[s], z)
+                v2p_cells(levels[s], z)   # one [V, 8] table per level: the devoxelize backward gathers over the p2v CSR
         if x.feats.is_cuda and min(int(levels[s].C.shape[0]) for s in levels) >= 2:
             # what the one-call pass (netprog / lt_net_forward) takes: every structure above as one struct of pointers
             from . import netprog
@@ -252,10 +252,10 @@ class SPVCNN(nn.Module):
                 self.prepare(x, backward=need_bwd)
                 cache, z = self._batch_cache(x)
                 maps = cache.get("net_maps")
-                if maps is not None and need_bwd and not maps.struct.v2p_perm[0]:
+                if maps is not None and need_bwd and not maps.struct.v2p_cells[0]:
                     # the batch was prepared for inference only: add what the backward reads
                     for s in (1, 16, 4):
-                        v2p_csr(cache["levels"][s], z)
+                        v2p_cells(cache["levels"][s], z)
                     maps = cache["net_maps"] = netprog.build_maps(cache, z, cache["levels"])
                 if maps is not None:
                     return netprog.run(prog, x.feats, maps, cache["levels"])

@@ -188,7 +188,7 @@ def test_one_call_backward_matches_the_module_path(scans_small):
 
 
 def test_batch_prepared_for_inference_gets_the_backward_structures_on_demand(scans_small):
-    """a no-grad pass does not build the devoxelize CSRs; a differentiated pass over the SAME batch adds them and gives
+    """a no-grad pass does not build the devoxelize cell tables; a differentiated pass over the SAME batch adds them and gives
     the gradients of a batch that had them from the start"""
     m = tta_model(0.5)
     net = m.net_3d
@@ -196,11 +196,11 @@ def test_batch_prepared_for_inference_gets_the_backward_structures_on_demand(sca
     with torch.no_grad():
         a = net(lidar)
     cache, z = net._batch_cache(lidar)
-    assert not cache["net_maps"].struct.v2p_perm[0] and "v2p_csr" not in z.additional_features
+    assert not cache["net_maps"].struct.v2p_cells[0] and "v2p_cells" not in z.additional_features
     torch.manual_seed(5)
     wgt = torch.randn_like(a)
     out = net(lidar)
-    assert cache["net_maps"].struct.v2p_perm[0]
+    assert cache["net_maps"].struct.v2p_cells[0]
     assert torch.equal(out.detach(), a)
     (out * wgt).sum().backward()
     got = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}

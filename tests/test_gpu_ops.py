@@ -461,6 +461,53 @@ def test_csr_scatter_kernels_match_atomic_kernels(scans_small):
     assert rel_err(b.cpu(), want) < 1e-6 and rel_err(a.cpu(), want) < 1e-6
 
 
+@pytest.mark.parametrize("s,C,drop", [(1, 32, 0.0), (4, 96, 0.0), (2, 32, 0.15), (16, 256, 0.0)])
+def test_devoxelize_backward_over_the_point_to_voxel_csr(s, C, drop):
+    """lt_devoxelize_cells + lt_devoxelize_cell_bwd (no CSR of the 8N-entry map: the points of a cell share their corner
+    voxels) against the atomic scatter kernel, the CSR kernel and a float64 index_add.  drop > 0 removes voxels from the
+    level: corners go missing (-1) and some points' own cell is no voxel (the atomically added remainder)."""
+    from latte_amd import ops
+    from latte_amd import point_voxel as pv
+    from latte_amd.tensor import PointTensor, SparseTensor
+    g = torch.Generator().manual_seed(11 * s + C)
+    N = 30000
+    pc = torch.cat([torch.rand(N, 3, generator=g) * torch.tensor([60.0, 50.0, 12.0]), torch.randint(0, 2, (N, 1), generator=g).float()], 1)
+    cell = torch.cat([torch.floor(pc[:, :3] / s).int() * s, pc[:, 3:].int()], 1)
+    corners = torch.cat([cell + torch.tensor([dx, dy, dz, 0], dtype=torch.int32) * s for dx in (0, 1) for dy in (0, 1) for dz in (0, 1)], 0)
+    vox = torch.unique(corners, dim=0)
+    vox = vox[torch.randperm(vox.shape[0], generator=g)]
+    if drop:
+        vox = vox[: int(vox.shape[0] * (1 - drop))]
+    V = vox.shape[0]
+    x = SparseTensor(torch.zeros(V, C).cuda(), vox.cuda(), s)
+    z = PointTensor(torch.zeros(N, C).cuda(), pc.cuda())
+    idx8, w8 = pv.v2p_index(x, z)
+    z.idx_query[x.s], z.weights[x.s] = idx8, w8
+    p2v, _ = pv.p2v_index(x, z)
+    assert bool((p2v < 0).any()) == bool(drop)
+    cells, p2v_csr, p2v_i = pv.v2p_cells(x, z)
+    # the table itself: cells[v, c] = the one cell whose corner c is v
+    cells_c, idx8_c, p2v_c = cells.cpu(), idx8.cpu().long(), p2v.cpu().long()
+    want_cells = torch.full((V, 8), -1, dtype=torch.int32)
+    ok = p2v_c >= 0
+    for c in range(8):
+        m = ok & (idx8_c[:, c] >= 0)
+        want_cells[idx8_c[m, c], c] = p2v_c[m].int()
+    assert torch.equal(cells_c, want_cells)
+    gout = torch.randn(N, C, generator=g).cuda()
+    got = ops.devoxelize_cell_bwd(gout, cells, p2v_csr, p2v_i, idx8, w8)
+    a = ops.devoxelize_bwd(gout, idx8, w8, V)
+    b = ops.devoxelize_csr_bwd(gout, ops.csr_build(idx8.reshape(-1), V), w8, V)
+    want = torch.zeros(V, C, dtype=torch.float64)
+    for c in range(8):
+        m = idx8_c[:, c] >= 0
+        want.index_add_(0, idx8_c[m, c], w8.cpu()[m, c].double().unsqueeze(1) * gout.cpu()[m].double())
+    tol = 3e-6   # sequential fp32 sums of up to ~4000 terms per voxel at stride 16
+    assert rel_err(got.cpu(), want) < tol and rel_err(a.cpu(), want) < tol and rel_err(b.cpu(), want) < tol
+    if not drop:   # no atomics involved: the same bits every time
+        assert torch.equal(got, ops.devoxelize_cell_bwd(gout, cells, p2v_csr, p2v_i, idx8, w8))
+
+
 @pytest.mark.parametrize("V,C", [(5000, 32), (777, 96), (33, 256)])
 def test_batch_norm_post_activation_add(V, C):
     """relu(bn(x)) + r in one kernel (lt_bn_apply relu = 3: the point branch of SPVCNN, z.F + point_transforms(z.F))
