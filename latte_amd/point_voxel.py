@@ -114,16 +114,9 @@ def voxel_to_point(x: SparseTensor, z: PointTensor, nearest: bool = False) -> Po
         af, idxq, s, n_vox = z.additional_features, z.idx_query, x.s, x.C.shape[0]
         csr = lambda: _v2p_cells(af, idxq, s, n_vox)
     if z.idx_query is None or z.weights is None or z.idx_query.get(x.s) is None or z.weights.get(x.s) is None:
-        idx_query, weights = v2p_index(x, z, nearest)
-        new_feat = LF.spdevoxelize(x.F, idx_query, weights, csr)
-        new_tensor = PointTensor(new_feat, z.C, idx_query=z.idx_query, weights=z.weights)
-        new_tensor.additional_features = z.additional_features
-        new_tensor.idx_query[x.s] = idx_query
-        new_tensor.weights[x.s] = weights
-        z.idx_query[x.s] = idx_query
-        z.weights[x.s] = weights
-    else:
-        new_feat = LF.spdevoxelize(x.F, z.idx_query.get(x.s), z.weights.get(x.s), csr)
-        new_tensor = PointTensor(new_feat, z.C, idx_query=z.idx_query, weights=z.weights)
-        new_tensor.additional_features = z.additional_features
+        # first use of this stride: the map is cached on the point tensor (and on every tensor derived from it)
+        z.idx_query[x.s], z.weights[x.s] = v2p_index(x, z, nearest)
+    new_feat = LF.spdevoxelize(x.F, z.idx_query[x.s], z.weights[x.s], csr)
+    new_tensor = PointTensor(new_feat, z.C, idx_query=z.idx_query, weights=z.weights)
+    new_tensor.additional_features = z.additional_features
     return new_tensor
