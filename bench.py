@@ -222,8 +222,9 @@ def hbm_classes(batch, w, hr):
     off = LF.get_kernel_offsets(3, 1, 1, device=dev)
     res = ops.kmap_build(x0.C, x0.C, off)
     M = int((res >= 0).sum())
-    add("kmap_query", _event_us(lambda: ops.kmap_build(x0.C, x0.C, off)), 16 * V + 16 * V + 8 * M,
-        "lt_kmap_build 3^3 stride 1 (table insert + 27 probes per voxel): 16Vin + 16Vout + 8M")
+    add("kmap_query", _event_us(lambda: ops.kmap_build(x0.C, x0.C, off, submanifold=True)), 16 * V + 16 * V + 8 * M,
+        "lt_kmap_build_sub 3^3 stride 1 (table insert + 14 probes per voxel, the other 13 offsets mirrored): "
+        "16Vin + 16Vout + 8M")
     # voxelize (scatter-mean point -> voxel as an atomic-free CSR gather), C = 32
     idx = z.additional_features["idx_query"][1]
     csr = z.additional_features["p2v_csr"][x0.s]

@@ -83,6 +83,13 @@ int64_t lt_kmap_workspace_bytes(int64_t Vin);
 int lt_kmap_build(const int32_t* coords_in, int64_t Vin, const int32_t* coords_out, int64_t Vout,
                   const int32_t* offsets, int32_t K, void* ws, int64_t ws_bytes, int32_t* results,
                   lt_stream_t stream);
+/* The same table for a submanifold conv (stride 1, odd kernel: basic_blocks.py:17,51,58 with stride 1, spvcnn.py:30,32):
+ * coords_in == coords_out == `coords` with UNIQUE rows, K odd and offsets[K-1-k] == -offsets[k] (torchsparse's
+ * get_kernel_offsets order has that property for odd kernels).  Then results[K-1-k, i] == o <=> results[k, o] == i, and
+ * K/2 + 1 probes per row fill the whole table (the other K/2 rows receive the mirrored hits).  Same bits as
+ * lt_kmap_build under those preconditions, which the caller guarantees (they are not checked on the device). No sync. */
+int lt_kmap_build_sub(const int32_t* coords, int64_t V, const int32_t* offsets, int32_t K, void* ws, int64_t ws_bytes,
+                      int32_t* results, lt_stream_t stream);
 /* torchsparse (nbmaps [M,2]=(in,out) k-major/out-ascending, nbsizes[K]) derived from `results`
  * (nonzero(results != -1) order).  nbmaps capacity K*Vout rows.  [sync] */
 int64_t lt_kmap_pairs_workspace_bytes(int64_t K, int64_t Vout);

@@ -34,6 +34,7 @@ SIGNATURES = {
     "lt_downsample_coords": (ctypes.c_int, [P, I64, I32, P, I64, P, PI64, P]),
     "lt_kmap_workspace_bytes": (I64, [I64]),
     "lt_kmap_build": (ctypes.c_int, [P, I64, P, I64, P, I32, P, I64, P, P]),
+    "lt_kmap_build_sub": (ctypes.c_int, [P, I64, P, I32, P, I64, P, P]),
     "lt_kmap_pairs_workspace_bytes": (I64, [I64, I64]),
     "lt_kmap_pairs": (ctypes.c_int, [P, I32, I64, P, I64, P, P, PI64, P]),
     "lt_kmap_reverse": (ctypes.c_int, [P, I32, I64, I64, P, P]),

@@ -134,6 +134,52 @@ extern "C" int lt_kmap_build(const int32_t* coords_in, int64_t Vin, const int32_
   return LT_OK;
 }
 
+// Submanifold map (coords_in IS coords_out, unique rows; K odd, offsets[K-1-k] = -offsets[k]): row i is the neighbour of
+// row o at offset k exactly when o is the neighbour of i at offset K-1-k, so one probe fills two entries.  One thread
+// per (k <= K/2, o): rows k < K/2 are probed and mirrored, the centre row is probed as it is; rows k > K/2 start at -1
+// (cleared by the caller) and receive only mirrored hits -- each entry has one writer because the rows are unique.
+__global__ void k_kmap_query_sym(const int* __restrict__ coords, int64_t V, const int* __restrict__ offsets, int K, LtTable t,
+                                 int* __restrict__ results) {
+  const int half = K / 2;
+  const int64_t total = V * (int64_t)(half + 1);
+  for (int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(g / V);
+    const int64_t o = g - (int64_t)k * V;
+    const int4 c = reinterpret_cast<const int4*>(coords)[o];
+    const uint64_t h = lt_fnv1a4(c.x + offsets[3 * k], c.y + offsets[3 * k + 1], c.z + offsets[3 * k + 2], c.w);
+    const int s = lt_table_find(t, h);
+    const int i = s < 0 ? -1 : t.vals[s];
+    results[g] = i;
+    if (i >= 0 && k < half) results[(int64_t)(K - 1 - k) * V + i] = (int)o;
+  }
+}
+
+extern "C" int lt_kmap_build_sub(const int32_t* coords, int64_t V, const int32_t* offsets, int32_t K, void* ws,
+                                 int64_t ws_bytes, int32_t* results, hipStream_t stream) {
+  LT_REQUIRE(V >= 0 && K >= 1 && K % 2 == 1, LT_ERR_ARG, "lt_kmap_build_sub: bad sizes (K = %d must be odd)", K);
+  LT_REQUIRE(V < INT_MAX, LT_ERR_RANGE, "lt_kmap_build_sub: more than 2^31 voxels");
+  if (V == 0) return LT_OK;
+  LT_REQUIRE(coords && offsets && ws && results, LT_ERR_ARG, "lt_kmap_build_sub: null pointer");
+  LT_REQUIRE(ws_bytes >= lt_kmap_workspace_bytes(V), LT_ERR_WORKSPACE, "lt_kmap_build_sub: workspace needs %lld bytes, got %lld",
+             (long long)lt_kmap_workspace_bytes(V), (long long)ws_bytes);
+  LtTable t = lt_table_view(ws, V);
+  int rc = lt_table_clear(t, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_kmap_insert, dim3(lt_grid(V, 256)), dim3(256), 0, stream, coords, V, t);
+  LT_LAUNCH_CHECK();
+  const int half = K / 2;
+  if (half == 0 || V < 32768) {  // small levels: the extra clear costs more than 13 probes per row save (same table)
+    hipLaunchKernelGGL(k_kmap_query, dim3(lt_grid(V * K, 256)), dim3(256), 0, stream, coords, V, offsets, K, t, results);
+    LT_LAUNCH_CHECK();
+    return LT_OK;
+  }
+  if (half > 0) LT_CHECK_HIP(hipMemsetAsync(results + (int64_t)(half + 1) * V, 0xFF, (size_t)half * V * sizeof(int32_t), stream));
+  hipLaunchKernelGGL(k_kmap_query_sym, dim3(lt_grid(V * (half + 1), 256)), dim3(256), 0, stream, coords, V, offsets, K, t,
+                     results);
+  LT_LAUNCH_CHECK();
+  return LT_OK;
+}
+
 // ---------------------------------------------------------------- (nbmaps, nbsizes) in torchsparse order
 struct HitFlag {
   __device__ int operator()(int r) const { return r >= 0 ? 1 : 0; }

@@ -151,7 +151,9 @@ def downsample_coords(coords: torch.Tensor, sample_stride: int) -> torch.Tensor:
     return out[:cnt.value]
 
 
-def kmap_build(coords_in: torch.Tensor, coords_out: torch.Tensor, offsets: torch.Tensor) -> torch.Tensor:
+def kmap_build(coords_in: torch.Tensor, coords_out: torch.Tensor, offsets: torch.Tensor, submanifold: bool = False) -> torch.Tensor:
+    """submanifold=True: coords_out IS coords_in (unique rows), K odd, offsets point-symmetric -> lt_kmap_build_sub, which
+    probes K/2 + 1 offsets per row and mirrors the hits (same table)."""
     coords_in = _chk(coords_in, torch.int32, "kmap coords_in")
     coords_out = _chk(coords_out, torch.int32, "kmap coords_out")
     offsets = _chk(offsets, torch.int32, "kmap offsets")
@@ -159,6 +161,11 @@ def kmap_build(coords_in: torch.Tensor, coords_out: torch.Tensor, offsets: torch
     lib = _lib.load()
     ws = _ws(lib.lt_kmap_workspace_bytes(Vin), coords_in.device)
     res = torch.empty((K, Vout), dtype=torch.int32, device=coords_in.device)
+    if submanifold:
+        if coords_out.data_ptr() != coords_in.data_ptr() or K % 2 != 1:
+            raise ValueError("kmap_build(submanifold=True): needs coords_out is coords_in and an odd kernel volume")
+        _lib.call("lt_kmap_build_sub", _p(coords_in), Vin, _p(offsets), K, _p(ws), ws.numel(), _p(res), _stream())
+        return res
     _lib.call("lt_kmap_build", _p(coords_in), Vin, _p(coords_out), Vout, _p(offsets), K, _p(ws), ws.numel(),
               _p(res), _stream())
     return res

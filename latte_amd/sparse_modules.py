@@ -44,8 +44,10 @@ def build_kernel_map(input: SparseTensor, kernel_size, stride, dilation):
             out_coords = ops.downsample_coords(coords, stride[0] * input.stride[0])
     else:
         out_coords = coords
-    results = ops.kmap_build(coords, out_coords, offsets)
+    # stride 1 and an odd kernel: same coordinate set on both sides, get_kernel_offsets is point-symmetric
+    # (offsets[K-1-k] = -offsets[k]) -> half the probes, the other half of the table mirrored
     sub = all(s == 1 for s in stride) and (offsets.shape[0] % 2 == 1)
+    results = ops.kmap_build(coords, out_coords, offsets, submanifold=sub)
     kmap = LF.KernelMap(results, coords.shape[0], out_coords.shape[0], submanifold=sub)
     input.kmaps[key] = kmap
     return kmap, out_coords

@@ -86,6 +86,35 @@ def test_kernel_map_bit_exact(scans_small, ks, stride):
     assert (rev != -1).sum() == kk.size
 
 
+@pytest.mark.parametrize("ks,ts", [(3, 1), (3, 4), ((1, 3, 3), 1), (5, 1), (1, 1)])
+def test_submanifold_kernel_map_from_half_the_probes(scans_small, ks, ts):
+    """lt_kmap_build_sub (K/2 + 1 probes per row, the other offsets mirrored) == lt_kmap_build == the oracle's table"""
+    from latte_amd import functional as LF
+    from latte_amd import ops
+    # above 32 768 rows the mirrored kernel runs, below it the plain query: 50 000 unique cells of a 60^3 x 2 block (~3
+    # neighbours per row) and the small scans
+    rng = np.random.default_rng(5)
+    cells = rng.choice(60 * 60 * 60 * 2, size=50000, replace=False)
+    big = np.stack([cells % 60, cells // 60 % 60, cells // 3600 % 60, cells // 216000], 1).astype(np.int32)
+    big[:, :3] *= ts
+    for c in (big, scans_small["coords"] if ts == 1 else ts_ref.spdownsample(ts_ref.spdownsample(scans_small["coords"], 2, 1), 2, 2)):
+        _check_sub_map(c, ks, ts)
+
+
+def _check_sub_map(c, ks, ts):
+    from latte_amd import functional as LF
+    from latte_amd import ops
+    cd = dev(c)
+    off = LF.get_kernel_offsets(ks, ts, 1, device=cd.device)
+    assert torch.equal(off, -off.flip(0))
+    full = ops.kmap_build(cd, cd, off)
+    half = ops.kmap_build(cd, cd, off, submanifold=True)
+    assert torch.equal(full, half)
+    if ks == 3:
+        _, _, _, res = ts_ref.build_kmap(c, ts, 3, 1)
+        assert np.array_equal(half.cpu().numpy(), res.astype(np.int32))
+
+
 @pytest.mark.parametrize("cin,cout", [(4, 32), (32, 32), (32, 64), (96, 96), (128, 96), (192, 128), (256, 256), (48, 48)])
 def test_spconv_forward_matches_oracle(scans_small, cin, cout):
     from latte_amd import ops
