@@ -56,6 +56,14 @@ int lt_st_gather_back(const float* voxel_ety, const int32_t* inverse, const int6
                       const int32_t* frame_seg, int32_t Wmax, const int64_t* seg_out_start, int64_t P, float* out,
                       lt_stream_t stream);
 
+/* The same when the frames of a window are NOT contiguous in the batch (a shuffled loader).  The reference then takes the
+ * hist rows sequentially from the window's first frame on (hr_module.py:203-220: init_hr_left = rows before
+ * min(corr_indices), then one slice per frame of that frame's size) and writes the entropies back to that row range
+ * (:256-259) -- SURVEY quirk Q5, reproduced as it is: segment s covers rows [seg_row_start[s], + its length).
+ * out[j] = mean over the segments that cover row j and see the element in range, in segment (= anchor) order. */
+int lt_st_gather_back_rows(const float* voxel_ety, const int32_t* inverse, const int64_t* seg_row_start /*[S]*/,
+                           const int64_t* seg_out_start /*[S+1]*/, int32_t S, int64_t P, float* out, lt_stream_t stream);
+
 /* Voxel-set intersection of anchor and hist voxels (replaces the dense [Va,Vt] compare of hr_module.py:271-283):
  * both key arrays are sorted ascending.  a_sel / t_sel (capacity min(Va,Vt)) receive the matched voxel ids in
  * ascending order (k-th entries correspond); *M (HOST) = number of matches.  [sync] */

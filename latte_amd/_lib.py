@@ -94,6 +94,7 @@ SIGNATURES = {
     "lt_segment_reduce": (ctypes.c_int, [P, I32, P, P, P, I64, I32, P, P, P]),
     "lt_segment_reduce_bwd": (ctypes.c_int, [P, I32, P, P, I64, I32, P, P]),
     "lt_st_gather_back": (ctypes.c_int, [P, P, P, I32, P, I32, P, I64, P, P]),
+    "lt_st_gather_back_rows": (ctypes.c_int, [P, P, P, P, I32, I64, P, P]),
     "lt_st_join_workspace_bytes": (I64, [I64, I64]),
     "lt_st_join": (ctypes.c_int, [P, I64, P, I64, P, I64, P, P, PI64, P]),
     "lt_class_quantile_workspace_bytes": (I64, [I64]),

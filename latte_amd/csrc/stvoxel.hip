@@ -378,6 +378,38 @@ extern "C" int lt_st_gather_back(const float* voxel_ety, const int32_t* inverse,
   return LT_OK;
 }
 
+// The same write-back when a window's frames are NOT contiguous in the batch: the reference then slices the hist rows
+// sequentially from the window's first frame on (hr_module.py:203-220, 256-259), so segment s covers the ROW range
+// [seg_row[s], seg_row[s] + n_s) whatever frame its points came from.  One thread per row, all S segments tested in
+// order (S <= anchors x window, ascending anchor: the reference's accumulation order).
+__global__ void k_st_gather_back_rows(const float* __restrict__ vety, const int* __restrict__ inverse,
+                                      const int64_t* __restrict__ seg_row, const int64_t* __restrict__ seg_out, int S, int64_t P,
+                                      float* __restrict__ out) {
+#pragma clang fp contract(off)
+  for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < P; j += (int64_t)gridDim.x * blockDim.x) {
+    float acc = 0.f;
+    int cnt = 0;
+    for (int s = 0; s < S; ++s) {
+      const int64_t d = j - seg_row[s];
+      if (d < 0 || d >= seg_out[s + 1] - seg_out[s]) continue;
+      const int v = inverse[seg_out[s] + d];
+      if (v >= 0) { acc = acc + vety[v]; ++cnt; }
+    }
+    out[j] = cnt > 0 ? acc / (float)cnt : 0.f;
+  }
+}
+
+extern "C" int lt_st_gather_back_rows(const float* voxel_ety, const int32_t* inverse, const int64_t* seg_row_start,
+                                      const int64_t* seg_out_start, int32_t S, int64_t P, float* out, hipStream_t stream) {
+  LT_REQUIRE(P >= 0 && S >= 1, LT_ERR_ARG, "lt_st_gather_back_rows: bad sizes");
+  if (P == 0) return LT_OK;
+  LT_REQUIRE(inverse && seg_row_start && seg_out_start && out, LT_ERR_ARG, "lt_st_gather_back_rows: null pointer");
+  hipLaunchKernelGGL(k_st_gather_back_rows, dim3(lt_grid(P, 256)), dim3(256), 0, stream, voxel_ety, inverse, seg_row_start,
+                     seg_out_start, S, P, out);
+  LT_LAUNCH_CHECK();
+  return LT_OK;
+}
+
 // ---------------------------------------------------------------- sorted-set join
 __global__ void k_join_probe(const int64_t* __restrict__ a, int64_t Va, const int64_t* __restrict__ t, int64_t Vt,
                              int* __restrict__ a_hit, unsigned char* __restrict__ a_flag, unsigned char* __restrict__ t_flag) {

@@ -125,18 +125,20 @@ class HR_Block(nn.Module):
         a_id, h_id = list(anchor_batch["scan_ID"]), list(hist_batch["scan_ID"])
         h_sizes = [int(hist_batch[hs_ref][j].shape[0]) for j in range(len(h_id))]
         h_start = np.concatenate([[0], np.cumsum(h_sizes)]).astype(np.int64)
-        segs = []  # (anchor, frame, src_start, n)
+        segs = []  # (anchor, frame, src_start, n, row_start)
         for i in range(len(a_id)):
             corr = [j for j in range(len(h_id))
                     if h_scene[j] == a_scene[i] and abs(float(h_id[j]) - float(a_id[i])) <= self.temp_bond]
             if not corr:
                 raise ValueError(f"HR_Block: anchor {i} has no frame of its scene in the hist batch")
-            if corr != list(range(corr[0], corr[-1] + 1)):
-                # the reference slices the hist logits sequentially from the first matching frame (quirk Q5) and is
-                # only meaningful for contiguous, ID-ordered windows, which is what its sequential loader produces
-                raise NotImplementedError("HR_Block: window frames must be contiguous in the batch (reference quirk Q5)")
+            # the reference takes the hist LOGITS (and writes the entropies back) sequentially from the first matching
+            # frame on, one slice per frame of that frame's size (hr_module.py:203-220,256-263: quirk Q5); the points
+            # come from the frame itself.  For a contiguous window (its sequential loader) row_start == src_start; the
+            # slices never run past the hist rows (they are no longer than the frames from corr[0] on).
+            row = int(h_start[corr[0]])
             for j in corr:
-                segs.append((i, j, int(h_start[j]), h_sizes[j]))
+                segs.append((i, j, int(h_start[j]), h_sizes[j], row))
+                row += h_sizes[j]
         return segs, h_start, h_sizes
 
     def geometry(self, anchor_batch: Dict, anchor_type: str, hist_batch: Dict, hist_type: str, device=None) -> Dict:
@@ -168,11 +170,11 @@ class HR_Block(nn.Module):
         poses_a = [torch.as_tensor(p, dtype=torch.float64).cpu() for p in anchor_batch["pose"]]
         poses_h = [torch.as_tensor(p, dtype=torch.float64).cpu() for p in hist_batch["pose"]]
         inv_a = [torch.linalg.inv(p) for p in poses_a]
-        seg_T = torch.stack([(inv_a[i] @ poses_h[j])[:3].reshape(12) for (i, j, _, _) in segs], 0)
+        seg_T = torch.stack([(inv_a[i] @ poses_h[j])[:3].reshape(12) for (i, j, _, _, _) in segs], 0)
         Wmax = max(sum(1 for s in segs if s[1] == j) for j in range(len(h_sizes)))
         frame_seg = np.full((len(h_sizes), max(Wmax, 1)), -1, dtype=np.int32)
         fill = [0] * len(h_sizes)
-        for si, (i, j, _, _) in enumerate(segs):  # segs are anchor-major => ascending anchor per frame
+        for si, (i, j, _, _, _) in enumerate(segs):  # segs are anchor-major => ascending anchor per frame
             frame_seg[j, fill[j]] = si
             fill[j] += 1
         a_start = np.concatenate([[0], np.cumsum(a_sizes)]).astype(np.int64)
@@ -194,6 +196,15 @@ class HR_Block(nn.Module):
                                     self.voxel_size, self.min_offset, cb)
         a_keys, _ = ops.st_keys(a_pts, a_seg_out_d, a_seg_out_d[:-1].contiguous(), a_seg_anchor_d, None, Pa,
                                 self.max_range, self.voxel_size, self.min_offset, cb)
+        contiguous = all(s[2] == s[4] for s in segs)
+        seg_row_d = None
+        if not contiguous:
+            # quirk Q5 (see _plan): element e of segment s stands for hist ROW row_start[s] + (e - seg_out[s]) -- its logits,
+            # its tr_p2v index and the row its entropy is written back to -- not for the point it was made from
+            seg_row_d = d(np.array([s[4] for s in segs], dtype=np.int64), torch.int64)
+            elem = torch.arange(E, device=dev, dtype=torch.int64)
+            seg_of = torch.bucketize(elem, seg_out_d[1:], right=True)
+            h_src = (seg_row_d[seg_of] + (elem - seg_out_d[seg_of])).to(torch.int32)
         h_selem, h_inv, h_uk, h_seg = ops.sort_segments(h_keys, key_bits)
         a_selem, a_inv, a_uk, a_seg = ops.sort_segments(a_keys, key_bits)
 
@@ -215,7 +226,8 @@ class HR_Block(nn.Module):
                     vox=_decode_xyz(matched_keys, cb), ac_p2v=ac_first[a_sel_l], tr_p2v=tr_first[t_sel_l],
                     row_anchor=(matched_keys >> (3 * cb)),
                     anchor_start=d(np.concatenate([[0], np.cumsum(per_anchor)]), torch.int32),
-                    h_start_d=d(h_start, torch.int64), frame_seg_d=d(frame_seg, torch.int32), seg_out_d=seg_out_d)
+                    h_start_d=d(h_start, torch.int64), frame_seg_d=d(frame_seg, torch.int32), seg_out_d=seg_out_d,
+                    seg_row_d=seg_row_d)
 
     def forward(self, anchor_batch: Dict, anchor_type: str, hist_batch: Dict, hist_type: str, geo: Dict = None) -> Dict:
         assert "seg_logit" in anchor_batch and "seg_logit" in hist_batch
@@ -237,7 +249,10 @@ class HR_Block(nn.Module):
         ac_voxel_probs = _VoxelMeanSoftmax.apply(a_in.contiguous(), geo["a_selem"], geo["a_inv"], geo["a_seg"])
 
         # ---- ST-voxel entropy written back to the hist points (mean over the anchors that see the point)
-        hs_pc_ety = ops.st_gather_back(tr_voxel_ety, geo["h_inv"], geo["h_start_d"], geo["frame_seg_d"], geo["seg_out_d"], Ph)
+        if geo.get("seg_row_d") is None:
+            hs_pc_ety = ops.st_gather_back(tr_voxel_ety, geo["h_inv"], geo["h_start_d"], geo["frame_seg_d"], geo["seg_out_d"], Ph)
+        else:   # non-contiguous windows: the write-back follows the reference's row slices
+            hs_pc_ety = ops.st_gather_back_rows(tr_voxel_ety, geo["h_inv"], geo["seg_row_d"], geo["seg_out_d"], Ph)
 
         vox = geo["vox"]
         split = lambda t: list(torch.split(t, per_anchor, 0))

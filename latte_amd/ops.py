@@ -618,6 +618,17 @@ def st_gather_back(voxel_ety, inverse, frame_start, frame_seg, seg_out_start, P:
     return out
 
 
+def st_gather_back_rows(voxel_ety, inverse, seg_row_start, seg_out_start, P: int):
+    """lt_st_gather_back_rows: the write-back over row ranges (windows whose frames are not contiguous in the batch)."""
+    S = seg_row_start.numel()
+    assert seg_out_start.numel() == S + 1
+    out = torch.empty(P, dtype=torch.float32, device=inverse.device)
+    _lib.call("lt_st_gather_back_rows", _p(_chk(voxel_ety, torch.float32, "voxel_ety")), _p(inverse),
+              _p(_chk(seg_row_start, torch.int64, "seg_row_start")), _p(_chk(seg_out_start, torch.int64, "seg_out_start")),
+              S, int(P), _p(out), _stream())
+    return out
+
+
 def st_join(a_keys, t_keys):
     """sorted int64 key arrays -> (a_sel int32 [M], t_sel int32 [M]) matched voxel ids, ascending."""
     a_keys = _chk(a_keys, torch.int64, "st_join a_keys")

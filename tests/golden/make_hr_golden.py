@@ -53,7 +53,7 @@ from latte.data.utils.refine_pseudo_labels import refine_ety, refine_pseudo_labe
 from latte_amd import synth  # noqa: E402
 
 
-def make_case(name, n, B, C, W, vs, R, beams, full_360, seq_len, seed, conf=0.75):
+def make_case(name, n, B, C, W, vs, R, beams, full_360, seq_len, seed, conf=0.75, interleave=0):
     g = torch.Generator().manual_seed(seed)
     pts, poses, scenes, ids, fov = [], [], [], [], []
     for b in range(B):
@@ -63,9 +63,12 @@ def make_case(name, n, B, C, W, vs, R, beams, full_360, seq_len, seed, conf=0.75
         # reference's own result is machine-dependent there.  Keep the fixture well-posed: nudge those points.
         p[np.abs(p[:, 1]) < 1e-6, 1] += 1e-3
         pts.append(torch.from_numpy(p))
-        poses.append(torch.from_numpy(synth.make_pose(b % seq_len)))
-        scenes.append(f"scene-{100 + b // seq_len:04d}")
-        ids.append(b % seq_len)
+        # interleave = k: the frames of k scenes alternate in the batch (a shuffled loader), so a window's frames are NOT
+        # contiguous and the reference slices the hist logits from the first matching frame on
+        scene, sid = (b % interleave, b // interleave) if interleave else (b // seq_len, b % seq_len)
+        poses.append(torch.from_numpy(synth.make_pose(sid)))
+        scenes.append(f"scene-{100 + scene:04d}")
+        ids.append(sid)
         keep = np.nonzero((p[:, 0] > 0) & (np.abs(p[:, 1]) < 0.8 * p[:, 0]))[0]
         fov.append(torch.from_numpy(keep))
     n_all = sum(p.shape[0] for p in pts)
@@ -139,6 +142,8 @@ CASES = {
     # BASELINE configs[0] at its own shape: ONE 32 768-point scan (B = 1: a single anchor whose window is itself), the
     # Synthia -> SemanticKITTI knobs of configs/synthia_semantic_kitti/latte.yaml:26-29 (W 3, R 40, vs 0.2, conf_perc 0.9)
     "b1_32k": dict(n=32768, B=1, C=9, W=3, vs=0.2, R=40, beams=64, full_360=False, seq_len=1, seed=4, conf=0.9),
+    # two scenes alternating in the batch: non-contiguous windows, the reference's sequential slicing (quirk Q5) as it is
+    "interleaved": dict(n=3072, B=6, C=9, W=3, vs=0.2, R=40, beams=32, full_360=False, seq_len=3, seed=6, interleave=2),
     # nuScenes USA -> Singapore knobs (configs/nuscenes/usa_singapore/latte.yaml:26-29): W 3, R 50, vs 0.2, conf_perc 0.5
     "nusc_cp05": dict(n=3072, B=6, C=16, W=3, vs=0.2, R=50, beams=32, full_360=True, seq_len=6, seed=5, conf=0.5),
 }

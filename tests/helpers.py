@@ -5,7 +5,7 @@ import numpy as np
 import torch
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-HR_CASES = ["tiny", "twoseq", "w5_360", "a2d2", "b1_32k", "nusc_cp05"]
+HR_CASES = ["tiny", "twoseq", "w5_360", "a2d2", "b1_32k", "nusc_cp05", "interleaved"]
 
 
 def load_hr_case(name):

@@ -82,11 +82,14 @@ def test_hr_window_plan_matches_reference_rule():
     pts = [torch.zeros(5, 3), torch.zeros(7, 3), torch.zeros(3, 3), torch.zeros(4, 3)]
     b = dict(scene_name=["scene-1", "scene-1", "scene-1", "scene-2"], scan_ID=[0, 1, 2, 0], ori_points=pts)
     segs, h_start, h_sizes = hr._plan(b, "ori_points", b, "ori_points")
-    assert [(a, f) for a, f, _, _ in segs] == [(0, 0), (0, 1), (1, 0), (1, 1), (1, 2), (2, 1), (2, 2), (3, 3)]
+    assert [(a, f) for a, f, _, _, _ in segs] == [(0, 0), (0, 1), (1, 0), (1, 1), (1, 2), (2, 1), (2, 2), (3, 3)]
+    assert all(src == row for _, _, src, _, row in segs)      # contiguous windows: logits rows == point rows
     assert h_start.tolist() == [0, 5, 12, 15, 19] and h_sizes == [5, 7, 3, 4]
+    # non-contiguous windows (a shuffled loader): the points come from the matching frames, the logit rows are taken
+    # sequentially from the first matching frame on, one slice per frame (hr_module.py:203-220, quirk Q5)
     b2 = dict(b, scene_name=["scene-1", "scene-2", "scene-1", "scene-2"])
-    with pytest.raises(NotImplementedError):   # non-contiguous window: the reference's slicing is undefined there (Q5)
-        hr._plan(b2, "ori_points", b2, "ori_points")
+    segs2, _, _ = hr._plan(b2, "ori_points", b2, "ori_points")
+    assert segs2 == [(0, 0, 0, 5, 0), (1, 1, 5, 7, 5), (1, 3, 15, 4, 12), (2, 2, 12, 3, 12), (3, 1, 5, 7, 5), (3, 3, 15, 4, 12)]
 
 
 def test_synthetic_workloads_cover_baseline_configs():
