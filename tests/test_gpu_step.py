@@ -55,6 +55,47 @@ def test_tta_iteration_matches_oracle():
     assert errs[len(errs) // 2] < 1e-2, errs[len(errs) // 2]
 
 
+def test_tta_iteration_on_a_shuffled_batch_matches_oracle():
+    """two sequences whose frames alternate in the batch (a shuffled loader): windows are not contiguous, HR_Block slices
+    the hist rows the reference's way (quirk Q5, hr_module.py:203-220); the whole step against the oracle's"""
+    from latte_amd import synth
+    from latte_amd.spvcnn import Net3DSeg
+    from latte_amd.tta_step import LatteStep
+    from latte_amd.workload import batch_from_raw, hr_cfg_of, make_raw
+    from oracle import step_ref
+    w = dict(synth.workload("tiny"), B=6, seq_len=3)
+    raw = make_raw(w)
+    perm = [0, 3, 1, 4, 2, 5]
+    raw = {k: [v[i] for i in perm] for k, v in raw.items()}
+    assert raw["scene_name"][0] != raw["scene_name"][1] and raw["scene_name"][0] == raw["scene_name"][2]
+    torch.manual_seed(1)
+    model = Net3DSeg(w["C"], True, "SPVCNN", {"cr": 0.5})
+    g = torch.Generator().manual_seed(2)
+    for mod in model.modules():
+        if isinstance(mod, torch.nn.BatchNorm1d):
+            mod.weight.data = 0.5 + torch.rand(mod.weight.shape, generator=g)
+            mod.bias.data = 0.2 * torch.randn(mod.bias.shape, generator=g)
+    model = model.cuda()
+    step = LatteStep(model, w["C"], hr_cfg_of(w))
+    batch = batch_from_raw(raw, w, device="cuda")
+    sd_s = {k: v.detach().cpu() for k, v in step.model.state_dict().items()}
+    sd_t = {k: v.detach().cpu() for k, v in step.ema_model.state_dict().items()}
+    got = {k: float(v) for k, v in step.forward_backward(batch).items()}
+    lidar = batch["lidar"]
+    want, _, g2d, _ = step_ref.tta_step_ref(
+        sd_s, sd_t, lidar.C.cpu().numpy(), lidar.F.cpu(), [i.cpu().numpy() for i in batch["inverse_map"]],
+        [int(i.shape[0]) for i in batch["indices"]], [p.cpu() for p in batch["ori_points"]],
+        [m.cpu() for m in batch["pc2img_idx"]], [p.numpy() for p in batch["pose"]], batch["scene_name"], batch["scan_ID"],
+        batch["logit_2d_student"].detach().cpu(), batch["logit_2d_teacher"].cpu(), hr_cfg_of(w), grad_names=[])
+    for k in ("hr_23", "hr_32"):
+        assert abs(got[k] - want[k]) < 1e-3 * abs(want[k]), (k, got[k], want[k])
+    for k in ("pl_2d", "pl_3d"):
+        assert abs(got[k] - want[k]) < 2e-3 * abs(want[k]), (k, got[k], want[k])
+    gq = batch["logit_2d_student"].grad.cpu()
+    assert float((gq - g2d).norm() / g2d.norm()) < 2e-3
+    step.close()
+
+
 def test_tta_iteration_gradients_match_oracle_to_1e3_under_shared_decisions():
     """The step-level gradient bar at 1e-3 (north_star), median AND worst, instead of the free-running 1e-2 above.
 
