@@ -84,6 +84,38 @@ def test_batchnorm_and_devoxelize_invariants(big):
     assert float(y.mean(0).abs().max()) < 1e-4 and float((y.var(0, unbiased=False) - 1).abs().max()) < 1e-3
 
 
+def test_devoxelize_backward_over_cells_is_the_adjoint_at_full_size(big):
+    """strides 1, 4, 16 of the 187 k-voxel batch, the maps SPVCNN.prepare builds: lt_devoxelize_cell_bwd against the atomic
+    scatter kernel, and <devox(x), g> == <x, devox^T(g)> (the property that does not need an oracle)"""
+    from latte_amd import ops
+    from latte_amd.spvcnn import SPVCNN
+    from latte_amd.tensor import SparseTensor
+    w, batch = big
+    lidar = batch["lidar"]
+    view = SparseTensor(lidar.F, lidar.C, lidar.s)
+    net = SPVCNN(cr=0.5).cuda()
+    net.prepare(view)
+    cache, z = net._batch_cache(view)
+    g = torch.Generator().manual_seed(2)
+    N = lidar.C.shape[0]
+    for s in (1, 4, 16):
+        s3 = (s, s, s)
+        V = cache["levels"][s].C.shape[0]
+        idx8, w8 = z.idx_query[s3], z.weights[s3]
+        cells = z.additional_features["v2p_cells"][s3]
+        p2v_csr, p2v_idx = z.additional_features["p2v_csr"][s3], z.additional_features["idx_query"][s3]
+        assert int((p2v_idx < 0).sum()) == 0                  # every point's cell is a voxel of the level
+        gout = torch.randn(N, 32, generator=g).cuda()
+        x = torch.randn(V, 32, generator=g).cuda()
+        got = ops.devoxelize_cell_bwd(gout, cells, p2v_csr, p2v_idx.int(), idx8.int(), w8)
+        ref = ops.devoxelize_bwd(gout, idx8.int(), w8, V)
+        assert float((got - ref).norm() / ref.norm()) < 1e-6, s
+        lhs = float((ops.devoxelize_fwd(x, idx8.int(), w8).double() * gout.double()).sum())
+        rhs = float((x.double() * got.double()).sum())
+        assert abs(lhs - rhs) < 1e-6 * max(abs(lhs), 1.0), (s, lhs, rhs)
+        assert torch.equal(got, ops.devoxelize_cell_bwd(gout, cells, p2v_csr, p2v_idx.int(), idx8.int(), w8))   # no atomics ran
+
+
 def test_full_size_step_is_finite_and_st_voxels_conserve_points(big):
     from latte_amd.hr_module import HR_Block
     from latte_amd.workload import hr_cfg_of
