@@ -73,7 +73,9 @@ int lt_st_join(const int64_t* a_keys, int64_t Va, const int64_t* t_keys, int64_t
 
 /* refine_ety (latte/data/utils/refine_pseudo_labels.py:33-53): per class c of label[0..n), thresh_c =
  * torch.quantile(ety[label==c], q) (linear interpolation, fp32); mask[j] = !(ety[j] > thresh_label[j]).
- * ety must be >= 0.  mask has n bytes. */
+ * ety must be >= 0.  mask has n bytes.  Up to 16 classes the thresholds come from a radix SELECTION (four 8-bit histogram
+ * passes over order-preserving keys find the two order statistics exactly; no sort), above that from a radix sort of
+ * (class, value) keys: the same thresholds either way.  No sync. */
 int64_t lt_class_quantile_workspace_bytes(int64_t n);
 int lt_class_quantile_mask(const float* ety, const int32_t* label, int64_t n, int32_t num_classes, float q, void* ws,
                            int64_t ws_bytes, uint8_t* mask, lt_stream_t stream);
@@ -97,8 +99,9 @@ int lt_pseudo_label_fuse(const float* logits_2d, const float* logits_3d, const i
                          lt_stream_t stream);
 
 /* torch.quantile(x, q) (linear interpolation) of a 1-D float array, result left on the device: out[0].  The thresholds
- * of latte/tta/tools/latte.py:214-215.  One keys-only 32-bit radix sort instead of torch's (key, index) sort; rank and
- * interpolation arithmetic as in ATen (fp32), so the result is torch's bit for bit on finite inputs.  No sync. */
+ * of latte/tta/tools/latte.py:214-215.  The two order statistics by radix selection (four 8-bit histogram passes, no
+ * sort; torch sorts (key, index) pairs); rank and interpolation arithmetic as in ATen (fp32), so the result is torch's bit
+ * for bit on finite inputs (-0 counts as +0).  No sync. */
 int64_t lt_quantile_workspace_bytes(int64_t n);
 int lt_quantile(const float* x, int64_t n, float q, void* ws, int64_t ws_bytes, float* out, lt_stream_t stream);
 

@@ -473,6 +473,214 @@ extern "C" int lt_st_join(const int64_t* a_keys, int64_t Va, const int64_t* t_ke
   return LT_OK;
 }
 
+// ---------------------------------------------------------------- order statistics by radix SELECTION (no sort)
+// torch.quantile / torch.median need one or two order statistics per class, not the sorted array: four 8-bit histogram
+// passes over order-preserving 32-bit keys, each over the elements whose leading bits equal the bits chosen so far, find
+// them exactly -- 10 small dispatches per call where the radix sort took ~25 (12 sort kernels + rocPRIM's own memsets),
+// all of them on the main stream between the teacher forward and the losses.  The values cluster (entropies of a
+// confident network sit in a handful of bins, and then nearly every element passes every prefix test), so every pass
+// counts in a per-workgroup LDS histogram -- a wave whose lanes all hit one counter adds once -- and flushes its
+// non-zero bins.  Up to SEL_MAX_CLASSES classes; beyond that the sort path.
+#define SEL_MAX_CLASSES 16
+#define SEL_NB 256
+struct SelState {
+  unsigned prefix[2];  // bits chosen so far for the two wanted ranks (mode 0: floor / ceil of q (cnt - 1); mode 1: the median twice)
+  unsigned rem[2];     // rank inside the chosen bin
+  unsigned cnt;        // elements of the class
+  unsigned pad[3];
+};
+
+__device__ __forceinline__ unsigned sel_key(float v) {
+  const unsigned b = __float_as_uint(v + 0.0f);  // -0 -> +0
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float sel_unkey(unsigned k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+
+// one counter bump per lane, or one per wave when every active lane of the wave wants the same counter
+__device__ __forceinline__ void sel_bump(unsigned* s_h, int slot) {
+  const int first = __builtin_amdgcn_readfirstlane(slot);
+  const unsigned long long same = __ballot(slot == first);
+  const unsigned long long act = __ballot(1);
+  if (same == act) {
+    if ((int)__lane_id() == __ffsll((long long)act) - 1) atomicAdd(s_h + first, (unsigned)__popcll(act));
+  } else {
+    atomicAdd(s_h + slot, 1u);
+  }
+}
+
+// hist[C][2][256] of byte LEVEL (0 = the most significant) over the elements whose higher bytes equal the query's prefix;
+// level 0 has no prefix and fills query 0 only.  label == NULL: one class.
+template <int LEVEL>
+__global__ __launch_bounds__(256) void k_sel_hist(const float* __restrict__ x, const int* __restrict__ label, int64_t n, int C,
+                                                  const SelState* __restrict__ st, unsigned* __restrict__ hist) {
+  __shared__ unsigned s_h[SEL_MAX_CLASSES * 2 * SEL_NB];
+  __shared__ unsigned s_pre[SEL_MAX_CLASSES * 2];
+  __shared__ unsigned s_cnt[SEL_MAX_CLASSES];
+  const int nb = C * 2 * SEL_NB;
+  for (int e = threadIdx.x; e < nb; e += 256) s_h[e] = 0;
+  if (LEVEL > 0 && threadIdx.x < C) {
+    s_pre[2 * threadIdx.x] = st[threadIdx.x].prefix[0];
+    s_pre[2 * threadIdx.x + 1] = st[threadIdx.x].prefix[1];
+    s_cnt[threadIdx.x] = st[threadIdx.x].cnt;
+  }
+  __syncthreads();
+  constexpr int SH = 24 - 8 * LEVEL;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int l = label ? label[i] : 0;
+    if (l < 0 || l >= C) continue;
+    const unsigned k = sel_key(x[i]);
+    const int bin = (int)((k >> SH) & 0xFFu);
+    if (LEVEL == 0) {
+      sel_bump(s_h, (l * 2) * SEL_NB + bin);
+    } else {
+      if (s_cnt[l] == 0) continue;
+      const unsigned lead = k >> (SH + 8);
+      const bool m0 = lead == s_pre[2 * l], m1 = lead == s_pre[2 * l + 1];
+      if (m0) sel_bump(s_h, (l * 2) * SEL_NB + bin);
+      if (m1) sel_bump(s_h, (l * 2 + 1) * SEL_NB + bin);
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < nb; e += 256) {
+    const unsigned v = s_h[e];
+    if (v) atomicAdd(hist + e, v);
+  }
+}
+
+// 256 threads, thread t owns bin t: the bin that holds rank r and r's rank inside it; *total = all counts.
+// r >= total: which / rem are undefined (the caller asks for the total only)
+__device__ void sel_locate(const unsigned* __restrict__ hist, unsigned r, unsigned* s_part, unsigned* which, unsigned* rem,
+                           unsigned* total) {
+  const int t = threadIdx.x;
+  const unsigned v = hist[t];
+  s_part[t] = v;
+  __syncthreads();
+  if (t < 64) {  // one wave: lane l scans bins 4l .. 4l+3, then a wave scan of the 64 sums
+    const unsigned a0 = s_part[4 * t], a1 = s_part[4 * t + 1], a2 = s_part[4 * t + 2], a3 = s_part[4 * t + 3];
+    const unsigned sum = a0 + a1 + a2 + a3;
+    unsigned inc = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned o = __shfl_up(inc, off, 64);
+      if (t >= off) inc += o;
+    }
+    const unsigned ex = inc - sum;
+    s_part[4 * t] = ex;
+    s_part[4 * t + 1] = ex + a0;
+    s_part[4 * t + 2] = ex + a0 + a1;
+    s_part[4 * t + 3] = ex + a0 + a1 + a2;
+    if (t == 63) s_part[256] = inc;
+  }
+  __syncthreads();
+  const unsigned lo = s_part[t];
+  if (v > 0 && r >= lo && r < lo + v) {  // exactly one thread when r < total
+    s_part[257] = (unsigned)t;
+    s_part[258] = r - lo;
+  }
+  __syncthreads();
+  *total = s_part[256];
+  *which = s_part[257];
+  *rem = s_part[258];
+  __syncthreads();
+}
+
+__device__ __forceinline__ void sel_ranks(unsigned cnt, float q, int mode, unsigned r[2]) {
+#pragma clang fp contract(off)
+  if (mode == 1) {
+    r[0] = r[1] = (cnt - 1) / 2;   // torch.median: the lower middle element
+  } else {
+    const float rank = q * (float)(cnt - 1);   // torch.quantile: fp32 rank, as in ATen
+    r[0] = (unsigned)floorf(rank);
+    r[1] = (unsigned)ceilf(rank);
+  }
+}
+
+// one block per class.  LEVEL 0: class count, the two ranks, their first byte.  LEVEL 1, 2: the next byte.
+// LEVEL 3: the last byte -> the two values -> thresh[c]: mode 0 torch.quantile(q) with ATen's lerp (empty class: +inf),
+// mode 1 min(torch.median, q) (empty: -inf)
+template <int LEVEL>
+__global__ __launch_bounds__(256) void k_sel_choose(const unsigned* __restrict__ hist, float q, int mode, SelState* __restrict__ st,
+                                                    float* __restrict__ thresh) {
+#pragma clang fp contract(off)
+  __shared__ unsigned s_part[260];
+  const int c = blockIdx.x;
+  const unsigned* h = hist + (int64_t)c * 2 * SEL_NB;
+  unsigned which, rem, total, w2[2], m2[2];
+  if (LEVEL == 0) {
+    sel_locate(h, 0xFFFFFFFFu, s_part, &which, &rem, &total);
+    if (total == 0) {
+      if (threadIdx.x == 0) st[c].cnt = 0;
+      return;
+    }
+    unsigned r[2];
+    sel_ranks(total, q, mode, r);
+    for (int qi = 0; qi < 2; ++qi) sel_locate(h, r[qi], s_part, &w2[qi], &m2[qi], &total);
+    if (threadIdx.x == 0) {
+      st[c].cnt = total;
+      st[c].prefix[0] = w2[0]; st[c].prefix[1] = w2[1];
+      st[c].rem[0] = m2[0]; st[c].rem[1] = m2[1];
+    }
+    return;
+  }
+  const SelState s = st[c];
+  if (s.cnt == 0) {
+    if (LEVEL == 3 && threadIdx.x == 0) thresh[c] = mode == 0 ? INFINITY : -INFINITY;
+    return;
+  }
+  for (int qi = 0; qi < 2; ++qi) sel_locate(h + qi * SEL_NB, s.rem[qi], s_part, &w2[qi], &m2[qi], &total);
+  if (threadIdx.x != 0) return;
+  const unsigned p0 = (s.prefix[0] << 8) | w2[0], p1 = (s.prefix[1] << 8) | w2[1];
+  if (LEVEL < 3) {
+    st[c].prefix[0] = p0; st[c].prefix[1] = p1;
+    st[c].rem[0] = m2[0]; st[c].rem[1] = m2[1];
+    return;
+  }
+  const float v0 = sel_unkey(p0), v1 = sel_unkey(p1);
+  if (mode == 1) {
+    thresh[c] = v0 < q ? v0 : q;
+    return;
+  }
+  const float rank = q * (float)(s.cnt - 1);
+  const float w = rank - floorf(rank);
+  const float d = v1 - v0;
+  thresh[c] = (w < 0.5f) ? (v0 + w * d) : (v1 - d * (1.0f - w));  // at::lerp
+}
+
+static int64_t sel_hist_ints(int C) { return (int64_t)4 * C * 2 * SEL_NB; }
+static int64_t sel_bytes(int C) { return sel_hist_ints(C) * 4 + lt_align_up((int64_t)C * sizeof(SelState), 256); }
+
+static bool sel_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("LT_QUANTILE_SORT");   // A/B and tests: 1 = the radix-sort path
+    return !(e && e[0] == '1');
+  }();
+  return on;
+}
+
+// thresholds of C classes (label NULL: one class) into thresh[C]; ws: sel_bytes(C)
+static int sel_thresholds(const float* x, const int32_t* label, int64_t n, int C, float q, int mode, void* ws, float* thresh,
+                          hipStream_t stream) {
+  unsigned* h = (unsigned*)ws;
+  const int64_t per = (int64_t)C * 2 * SEL_NB;
+  SelState* st = (SelState*)(h + 4 * per);
+  LT_CHECK_HIP(hipMemsetAsync(ws, 0, (size_t)sel_hist_ints(C) * 4, stream));
+  int blocks = (int)((n + 256 * 8 - 1) / (256 * 8));
+  blocks = blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks);
+  const dim3 g(blocks), b(256), gc(C);
+  hipLaunchKernelGGL(k_sel_hist<0>, g, b, 0, stream, x, label, n, C, (const SelState*)st, h);
+  hipLaunchKernelGGL(k_sel_choose<0>, gc, b, 0, stream, (const unsigned*)h, q, mode, st, thresh);
+  hipLaunchKernelGGL(k_sel_hist<1>, g, b, 0, stream, x, label, n, C, (const SelState*)st, h + per);
+  hipLaunchKernelGGL(k_sel_choose<1>, gc, b, 0, stream, (const unsigned*)(h + per), q, mode, st, thresh);
+  hipLaunchKernelGGL(k_sel_hist<2>, g, b, 0, stream, x, label, n, C, (const SelState*)st, h + 2 * per);
+  hipLaunchKernelGGL(k_sel_choose<2>, gc, b, 0, stream, (const unsigned*)(h + 2 * per), q, mode, st, thresh);
+  hipLaunchKernelGGL(k_sel_hist<3>, g, b, 0, stream, x, label, n, C, (const SelState*)st, h + 3 * per);
+  hipLaunchKernelGGL(k_sel_choose<3>, gc, b, 0, stream, (const unsigned*)(h + 3 * per), q, mode, st, thresh);
+  LT_LAUNCH_CHECK();
+  return LT_OK;
+}
+
 // ---------------------------------------------------------------- class-wise quantile mask (refine_ety)
 // labels outside [0, num_classes) (an ignore label such as -100, or a class the caller did not count) belong to no class:
 // they sort into the segment 0xFFFF, which no threshold is computed for, and k_cq_mask keeps them
@@ -535,7 +743,9 @@ static int64_t cq_sort_bytes(int64_t n) {
 
 extern "C" int64_t lt_class_quantile_workspace_bytes(int64_t n) {
   if (n < 1) n = 1;
-  return 2 * lt_align_up(n * 8, 256) + lt_align_up(cq_sort_bytes(n), 256) + 65536 * 4 + 1024;
+  const int64_t sort_path = 2 * lt_align_up(n * 8, 256) + lt_align_up(cq_sort_bytes(n), 256) + 65536 * 4 + 1024;
+  const int64_t select_path = sel_bytes(SEL_MAX_CLASSES) + 65536 * 4 + 1024;
+  return sort_path > select_path ? sort_path : select_path;
 }
 
 static int class_mask_impl(const float* ety, const int32_t* label, int64_t n, int32_t num_classes, float q, int mode,
@@ -559,6 +769,16 @@ static int class_mask_impl(const float* ety, const int32_t* label, int64_t n, in
   LT_REQUIRE(ety && label && ws && mask, LT_ERR_ARG, "lt_class_quantile_mask: null pointer");
   LT_REQUIRE(ws_bytes >= lt_class_quantile_workspace_bytes(n), LT_ERR_WORKSPACE, "lt_class_quantile_mask: workspace too small");
   LtArena a(ws, ws_bytes);
+  if (num_classes <= SEL_MAX_CLASSES && n < (1ll << 32) && sel_enabled()) {   // selection: no sort (same thresholds)
+    float* th = (float*)a.take((int64_t)num_classes * 4);
+    void* sw = a.take(sel_bytes(num_classes));
+    LT_REQUIRE(th && sw, LT_ERR_WORKSPACE, "lt_class_quantile_mask: arena exhausted");
+    const int rc = sel_thresholds(ety, label, n, num_classes, q, mode, sw, th, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_cq_mask, dim3(lt_grid(n, 256)), dim3(256), 0, stream, ety, label, n, th, num_classes, mode, mask);
+    LT_LAUNCH_CHECK();
+    return LT_OK;
+  }
   int64_t* keys = (int64_t*)a.take(n * 8);
   int64_t* skeys = (int64_t*)a.take(n * 8);
   float* thresh = (float*)a.take((int64_t)num_classes * 4);
@@ -704,7 +924,9 @@ static int64_t q_sort_bytes(int64_t n) {
 
 extern "C" int64_t lt_quantile_workspace_bytes(int64_t n) {
   if (n < 1) n = 1;
-  return 2 * lt_align_up(n * 4, 256) + lt_align_up(q_sort_bytes(n), 256) + 1024;
+  const int64_t sort_path = 2 * lt_align_up(n * 4, 256) + lt_align_up(q_sort_bytes(n), 256) + 1024;
+  const int64_t select_path = sel_bytes(1) + 1024;
+  return sort_path > select_path ? sort_path : select_path;
 }
 
 extern "C" int lt_quantile(const float* x, int64_t n, float q, void* ws, int64_t ws_bytes, float* out,
@@ -715,6 +937,11 @@ extern "C" int lt_quantile(const float* x, int64_t n, float q, void* ws, int64_t
   LT_REQUIRE(x && ws && out, LT_ERR_ARG, "lt_quantile: null pointer");
   LT_REQUIRE(ws_bytes >= lt_quantile_workspace_bytes(n), LT_ERR_WORKSPACE, "lt_quantile: workspace too small");
   LtArena a(ws, ws_bytes);
+  if (sel_enabled()) {   // two histogram passes instead of the sort: the same two order statistics, the same lerp
+    void* sw = a.take(sel_bytes(1));
+    LT_REQUIRE(sw, LT_ERR_WORKSPACE, "lt_quantile: arena exhausted");
+    return sel_thresholds(x, nullptr, n, 1, q, 0, sw, out, stream);
+  }
   unsigned* keys = (unsigned*)a.take(n * 4);
   unsigned* skeys = (unsigned*)a.take(n * 4);
   const int64_t sb = q_sort_bytes(n);

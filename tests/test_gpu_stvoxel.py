@@ -197,6 +197,42 @@ def test_quantile_matches_torch(n, q):
     assert torch.allclose(got, want, rtol=1e-6, atol=1e-7), (float(got), float(want))
 
 
+@pytest.mark.parametrize("C", [1, 9, 16, 17])
+@pytest.mark.parametrize("q", [0.0, 0.5, 0.75, 1.0])
+def test_class_quantile_and_median_masks_match_torch_on_hard_inputs(C, q):
+    """the per-class thresholds (radix selection for <= 16 classes, radix sort above) against torch.quantile / torch.median:
+    classes with 0, 1, 2 elements, one class of identical values, ties across the bins' boundaries, ignored labels"""
+    from latte_amd import ops
+    g = torch.Generator().manual_seed(100 * C + int(q * 100))
+    n = 40000
+    lab = torch.randint(0, C, (n,), generator=g)
+    ety = torch.rand(n, generator=g) * 2.5
+    ety[torch.rand(n, generator=g) < 0.2] = 0.0                        # no ST voxel: exactly 0
+    ety[torch.rand(n, generator=g) < 0.1] = 1.0                        # a tie at a power of two (a bin boundary of every level)
+    if C >= 9:
+        lab[lab == 3] = 4                                              # class 3: empty
+        lab[:1] = 3                                                    # ... no: ONE element
+        lab[lab == 5] = 6
+        lab[1:3] = 5                                                   # class 5: two elements
+        ety[lab == 7] = 0.625                                          # class 7: all values equal
+        lab[lab == 8] = 2                                              # class 8: empty
+    lab[torch.rand(n, generator=g) < 0.05] = -100                      # ignore label: kept, in no class
+    ety_d, lab_d = ety.cuda(), lab.int().cuda()
+    got = ops.class_quantile_mask(ety_d, lab_d, C, q).bool().cpu()
+    keep = ops.class_median_mask(ety_d, lab_d, C, 0.9).bool().cpu()
+    want, want_keep = torch.ones(n, dtype=torch.bool), torch.ones(n, dtype=torch.bool)
+    for c in range(C):
+        sel = lab == c
+        if not sel.any():
+            continue
+        t = torch.quantile(ety_d[sel.cuda()], q).cpu()                 # on the device, like the product (same lerp)
+        want[sel] = ~(ety[sel] > t)
+        med = min(float(ety[sel].median()), 0.9)
+        want_keep[sel] = ~(ety[sel] < med)
+    assert torch.equal(got, want)
+    assert torch.equal(keep, want_keep)
+
+
 def test_quantile_rejects_bad_arguments():
     from latte_amd import ops
     with pytest.raises(RuntimeError):
