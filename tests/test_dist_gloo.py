@@ -102,7 +102,7 @@ def _shard_worker(rank, world, port, out):
     hr = HR_Block(**hr_cfg_of(w))
     fake = dict(scene_name=scenes, scan_ID=ids, ori_points=[torch.zeros(1, 3)] * len(scans))
     segs, _, _ = hr._plan(fake, "ori_points", fake, "ori_points")
-    ok = ok and all(scenes[i] == scenes[j] and abs(ids[i] - ids[j]) <= w["W"] // 2 for i, j, _, _ in segs)
+    ok = ok and all(scenes[i] == scenes[j] and abs(ids[i] - ids[j]) <= w["W"] // 2 for i, j, _, _, _ in segs) and all(src == row for _, _, src, _, row in segs)
     want = sum(min(L - 1, i + w["W"] // 2) - max(0, i - w["W"] // 2) + 1 for i in range(L)) * ns
     ok = ok and len(segs) == want
     out[rank] = bool(ok)
