@@ -297,12 +297,13 @@ int lt_devoxelize_csr_bwd(const float* gout, const int32_t* perm, const int32_t*
 /* The same backward WITHOUT a CSR of the devoxelize map (F.spdevoxelize's backward, torchsparse_utils.py:81,93).  All points
  * of one cell (floor(z.C / s), the point -> voxel map of the level: torchsparse_utils.py:40-47 and :69-76 hash the same
  * floor coordinates) share their 8 corner voxels, so the points that reach voxel v through corner c are the points of ONE
- * cell: cells[V,8] (-1: none), filled by lt_devoxelize_cells from the first point of every row of the point -> voxel CSR
- * (p2v_perm / p2v_off over Vp rows, lt_csr_build of p2v_idx[N]).  lt_devoxelize_cell_bwd then sums, per voxel, corner by
- * corner and point-ascending inside a cell (deterministic; a different fp32 order than lt_devoxelize_csr_bwd's
- * point-major one).  Points with p2v_idx < 0 (their cell is no voxel of the level) are added atomically afterwards. */
+ * cell: cells[V,8,2] = that cell's row range [j0, j1) of the point -> voxel CSR ((0,0): none), filled by
+ * lt_devoxelize_cells from the first point of every CSR row (p2v_perm / p2v_off over Vp rows, lt_csr_build of
+ * p2v_idx[N]).  lt_devoxelize_cell_bwd then sums, per voxel, corner by corner and point-ascending inside a cell
+ * (deterministic; a different fp32 order than lt_devoxelize_csr_bwd's point-major one).  Points with p2v_idx < 0 (their
+ * cell is no voxel of the level) are added atomically afterwards. */
 int lt_devoxelize_cells(const int32_t* v2p_idx /*[N,8]*/, const int32_t* p2v_perm, const int32_t* p2v_off /*[Vp+1]*/,
-                        int32_t* cells /*[V,8]*/, int64_t N, int64_t Vp, int64_t V, lt_stream_t stream);
+                        int32_t* cells /*[V,8,2]*/, int64_t N, int64_t Vp, int64_t V, lt_stream_t stream);
 int lt_devoxelize_cell_bwd(const float* gout, const int32_t* cells, const int32_t* p2v_perm, const int32_t* p2v_off,
                            const int32_t* p2v_idx /*[N]*/, const int32_t* v2p_idx /*[N,8]*/, const float* w /*[N,8]*/,
                            float* gfeats /*[V,C]*/, int64_t N, int64_t V, int32_t C, lt_stream_t stream);

@@ -358,57 +358,72 @@ extern "C" int lt_devoxelize_csr_bwd(const float* gout, const int32_t* perm, con
 // points of ONE cell, cells[v, c], and the backward needs no CSR of its own (lt_csr_build over 8N keys: three radix sorts
 // of 6.3 M keys per batch at the a2d2 sizes) -- only this [V, 8] table, filled from the first point of every cell.
 __global__ void k_devox_cells(const int* __restrict__ idx, const int* __restrict__ pperm, const int* __restrict__ poff,
-                              int* __restrict__ cells, int64_t Vp, int64_t V) {
+                              int2* __restrict__ cells, int64_t Vp, int64_t V) {
   const int64_t total = Vp * 8;
   for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
     const int64_t u = e >> 3;
     const int c = (int)(e & 7);
-    const int j0 = poff[u];
-    if (poff[u + 1] <= j0) continue;
+    const int j0 = poff[u], j1 = poff[u + 1];
+    if (j1 <= j0) continue;
     const int v = idx[(int64_t)pperm[j0] * 8 + c];
-    if (v >= 0 && v < V) cells[(int64_t)v * 8 + c] = (int)u;  // one writer: u = the cell at v - offset_c
+    if (v >= 0 && v < V) cells[(int64_t)v * 8 + c] = make_int2(j0, j1);  // one writer: u = the cell at v - offset_c
   }
 }
 
-// gfeats[v,:] = sum_c sum_{p in cell cells[v,c], ascending} w[p,c] * gout[p,:]
-__global__ void k_devox_cell_bwd(const float* __restrict__ g, const int* __restrict__ cells, const int* __restrict__ pperm,
-                                 const int* __restrict__ poff, const float* __restrict__ w, float* __restrict__ gf, int64_t V,
-                                 int C4) {
+// gfeats[v,:] = sum_c sum_{j in cells[v,c]} w[pperm[j],c] * gout[pperm[j],:]   (corner by corner, points ascending)
+// The first point of all 8 rows is fetched up front (most cells of the fine levels hold one or two points: 8 independent
+// gathers in flight instead of 8 dependent chains); the sum is still formed in (corner, point) order.
+__global__ void k_devox_cell_bwd(const float* __restrict__ g, const int2* __restrict__ cells, const int* __restrict__ pperm,
+                                 const float* __restrict__ w, float* __restrict__ gf, int64_t V, int C4) {
 #pragma clang fp contract(off)
   const int64_t total = V * (int64_t)C4;
   for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
     const int64_t v = e / C4;
     const int c4 = (int)(e - v * C4);
-    const int4 ua = reinterpret_cast<const int4*>(cells)[v * 2], ub = reinterpret_cast<const int4*>(cells)[v * 2 + 1];
-    const int u[8] = {ua.x, ua.y, ua.z, ua.w, ub.x, ub.y, ub.z, ub.w};
-    int j0[8], j1[8];
+    int2 seg[8];
+    const int4* cv = reinterpret_cast<const int4*>(cells + v * 8);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int4 t = cv[c];
+      seg[2 * c] = make_int2(t.x, t.y);
+      seg[2 * c + 1] = make_int2(t.z, t.w);
+    }
+    int p0[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) p0[c] = seg[c].x < seg[c].y ? pperm[seg[c].x] : -1;
+    float w0[8];
+    float4 x0[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-      j0[c] = u[c] >= 0 ? poff[u[c]] : 0;
-      j1[c] = u[c] >= 0 ? poff[u[c] + 1] : 0;
+      const int p = p0[c] < 0 ? 0 : p0[c];
+      w0[c] = p0[c] < 0 ? 0.f : w[(int64_t)p * 8 + c];
+      x0[c] = p0[c] < 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : reinterpret_cast<const float4*>(g + (int64_t)p * C4 * 4)[c4];
     }
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-      int j = j0[c];
-      for (; j + 4 <= j1[c]; j += 4) {  // 4 gathers in flight, adds in ascending point order
-        const int p0 = pperm[j], p1 = pperm[j + 1], p2 = pperm[j + 2], p3 = pperm[j + 3];
-        const float w0 = w[(int64_t)p0 * 8 + c], w1 = w[(int64_t)p1 * 8 + c], w2 = w[(int64_t)p2 * 8 + c],
-                    w3 = w[(int64_t)p3 * 8 + c];
-        const float4 x0 = reinterpret_cast<const float4*>(g + (int64_t)p0 * C4 * 4)[c4];
-        const float4 x1 = reinterpret_cast<const float4*>(g + (int64_t)p1 * C4 * 4)[c4];
-        const float4 x2 = reinterpret_cast<const float4*>(g + (int64_t)p2 * C4 * 4)[c4];
-        const float4 x3 = reinterpret_cast<const float4*>(g + (int64_t)p3 * C4 * 4)[c4];
-        acc.x += w0 * x0.x; acc.y += w0 * x0.y; acc.z += w0 * x0.z; acc.w += w0 * x0.w;
-        acc.x += w1 * x1.x; acc.y += w1 * x1.y; acc.z += w1 * x1.z; acc.w += w1 * x1.w;
-        acc.x += w2 * x2.x; acc.y += w2 * x2.y; acc.z += w2 * x2.z; acc.w += w2 * x2.w;
-        acc.x += w3 * x3.x; acc.y += w3 * x3.y; acc.z += w3 * x3.z; acc.w += w3 * x3.w;
+      if (p0[c] < 0) continue;
+      acc.x += w0[c] * x0[c].x; acc.y += w0[c] * x0[c].y; acc.z += w0[c] * x0[c].z; acc.w += w0[c] * x0[c].w;
+      int j = seg[c].x + 1;
+      const int j1 = seg[c].y;
+      for (; j + 4 <= j1; j += 4) {  // 4 gathers in flight, adds in ascending point order
+        const int q0 = pperm[j], q1 = pperm[j + 1], q2 = pperm[j + 2], q3 = pperm[j + 3];
+        const float a0 = w[(int64_t)q0 * 8 + c], a1 = w[(int64_t)q1 * 8 + c], a2 = w[(int64_t)q2 * 8 + c],
+                    a3 = w[(int64_t)q3 * 8 + c];
+        const float4 y0 = reinterpret_cast<const float4*>(g + (int64_t)q0 * C4 * 4)[c4];
+        const float4 y1 = reinterpret_cast<const float4*>(g + (int64_t)q1 * C4 * 4)[c4];
+        const float4 y2 = reinterpret_cast<const float4*>(g + (int64_t)q2 * C4 * 4)[c4];
+        const float4 y3 = reinterpret_cast<const float4*>(g + (int64_t)q3 * C4 * 4)[c4];
+        acc.x += a0 * y0.x; acc.y += a0 * y0.y; acc.z += a0 * y0.z; acc.w += a0 * y0.w;
+        acc.x += a1 * y1.x; acc.y += a1 * y1.y; acc.z += a1 * y1.z; acc.w += a1 * y1.w;
+        acc.x += a2 * y2.x; acc.y += a2 * y2.y; acc.z += a2 * y2.z; acc.w += a2 * y2.w;
+        acc.x += a3 * y3.x; acc.y += a3 * y3.y; acc.z += a3 * y3.z; acc.w += a3 * y3.w;
       }
-      for (; j < j1[c]; ++j) {
-        const int p = pperm[j];
-        const float wk = w[(int64_t)p * 8 + c];
-        const float4 x = reinterpret_cast<const float4*>(g + (int64_t)p * C4 * 4)[c4];
-        acc.x += wk * x.x; acc.y += wk * x.y; acc.z += wk * x.z; acc.w += wk * x.w;
+      for (; j < j1; ++j) {
+        const int q = pperm[j];
+        const float a = w[(int64_t)q * 8 + c];
+        const float4 y = reinterpret_cast<const float4*>(g + (int64_t)q * C4 * 4)[c4];
+        acc.x += a * y.x; acc.y += a * y.y; acc.z += a * y.z; acc.w += a * y.w;
       }
     }
     reinterpret_cast<float4*>(gf)[e] = acc;
@@ -435,10 +450,11 @@ extern "C" int lt_devoxelize_cells(const int32_t* v2p_idx, const int32_t* p2v_pe
   LT_REQUIRE(N >= 0 && Vp >= 0 && V >= 0, LT_ERR_ARG, "lt_devoxelize_cells: bad sizes");
   if (V == 0) return LT_OK;
   LT_REQUIRE(cells, LT_ERR_ARG, "lt_devoxelize_cells: null pointer");
-  LT_CHECK_HIP(hipMemsetAsync(cells, 0xFF, V * 8 * sizeof(int32_t), stream));
+  LT_CHECK_HIP(hipMemsetAsync(cells, 0, V * 8 * 2 * sizeof(int32_t), stream));   // (0, 0): an empty row
   if (N == 0 || Vp == 0) return LT_OK;
   LT_REQUIRE(v2p_idx && p2v_perm && p2v_off, LT_ERR_ARG, "lt_devoxelize_cells: null pointer");
-  hipLaunchKernelGGL(k_devox_cells, dim3(lt_grid(Vp * 8, 256)), dim3(256), 0, stream, v2p_idx, p2v_perm, p2v_off, cells, Vp, V);
+  hipLaunchKernelGGL(k_devox_cells, dim3(lt_grid(Vp * 8, 256)), dim3(256), 0, stream, v2p_idx, p2v_perm, p2v_off, (int2*)cells,
+                     Vp, V);
   LT_LAUNCH_CHECK();
   return LT_OK;
 }
@@ -450,8 +466,8 @@ extern "C" int lt_devoxelize_cell_bwd(const float* gout, const int32_t* cells, c
   if (V == 0) return LT_OK;
   LT_REQUIRE(gout && cells && p2v_perm && p2v_off && p2v_idx && v2p_idx && w && gfeats, LT_ERR_ARG,
              "lt_devoxelize_cell_bwd: null pointer");
-  hipLaunchKernelGGL(k_devox_cell_bwd, dim3(lt_grid(V * (C / 4), 256)), dim3(256), 0, stream, gout, cells, p2v_perm, p2v_off,
-                     w, gfeats, V, C / 4);
+  hipLaunchKernelGGL(k_devox_cell_bwd, dim3(lt_grid(V * (C / 4), 256)), dim3(256), 0, stream, gout, (const int2*)cells,
+                     p2v_perm, w, gfeats, V, C / 4);
   LT_LAUNCH_CHECK();
   if (N > 0) {
     hipLaunchKernelGGL(k_devox_unmapped, dim3(lt_grid(N, 256)), dim3(256), 0, stream, gout, p2v_idx, v2p_idx, w, gfeats, N, V,

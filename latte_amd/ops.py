@@ -469,12 +469,12 @@ def devoxelize_csr_bwd(gout, csr, w, V: int):
 
 
 def devoxelize_cells(v2p_idx, p2v_csr, V: int):
-    """lt_devoxelize_cells: [V, 8] table "which cell reaches voxel v through corner c" from the point -> voxel CSR."""
+    """lt_devoxelize_cells: [V, 8, 2] table "CSR row range of the cell that reaches voxel v through corner c"."""
     v2p_idx = _chk(v2p_idx, torch.int32, "devox_cells idx")
     perm, off = p2v_csr
     N = v2p_idx.shape[0]
     assert v2p_idx.shape[1] == 8 and perm.numel() <= N
-    cells = torch.empty((V, 8), dtype=torch.int32, device=v2p_idx.device)
+    cells = torch.empty((V, 8, 2), dtype=torch.int32, device=v2p_idx.device)
     _lib.call("lt_devoxelize_cells", _p(v2p_idx), _p(perm), _p(off), _p(cells), N, off.numel() - 1, V, _stream())
     return cells
 

@@ -515,13 +515,15 @@ def test_devoxelize_backward_over_the_point_to_voxel_csr(s, C, drop):
     p2v, _ = pv.p2v_index(x, z)
     assert bool((p2v < 0).any()) == bool(drop)
     cells, p2v_csr, p2v_i = pv.v2p_cells(x, z)
-    # the table itself: cells[v, c] = the one cell whose corner c is v
+    # the table itself: cells[v, c] = CSR row range of the one cell whose corner c is v ((0, 0): none)
     cells_c, idx8_c, p2v_c = cells.cpu(), idx8.cpu().long(), p2v.cpu().long()
-    want_cells = torch.full((V, 8), -1, dtype=torch.int32)
+    off_c = p2v_csr[1].cpu()
+    want_cells = torch.zeros((V, 8, 2), dtype=torch.int32)
     ok = p2v_c >= 0
     for c in range(8):
         m = ok & (idx8_c[:, c] >= 0)
-        want_cells[idx8_c[m, c], c] = p2v_c[m].int()
+        want_cells[idx8_c[m, c], c, 0] = off_c[p2v_c[m]]
+        want_cells[idx8_c[m, c], c, 1] = off_c[p2v_c[m] + 1]
     assert torch.equal(cells_c, want_cells)
     gout = torch.randn(N, C, generator=g).cuda()
     got = ops.devoxelize_cell_bwd(gout, cells, p2v_csr, p2v_i, idx8, w8)
